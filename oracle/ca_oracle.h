@@ -1,0 +1,100 @@
+/* oracle/ca_oracle.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * C API of the CPU restatement of the reference's per-step hot path
+ * (gym_collision_avoidance/envs/collision_avoidance_env.py:156-234 `step`, :236-282 `reset`).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the reported CPU baseline -- never as the product path.
+ *
+ * Everything is float64 like the reference's Python, except (a) the ORCA arithmetic, which is
+ * C float like the rvo2 library (orca_ref.h; PARITY UNPINNED, see that header), and (b) the
+ * action pair, which the reference rounds to float32 (`all_actions` is a float32 array,
+ * collision_avoidance_env.py:305-307).
+ */
+#ifndef ORACLE_CA_ORACLE_H_
+#define ORACLE_CA_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flag word (one per agent) */
+enum {
+  ORC_AT_GOAL = 1u << 0,          /* agent.is_at_goal               (agent.py:150-153) */
+  ORC_WAS_AT_GOAL = 1u << 1,      /* agent.was_at_goal_already      (agent.py:203-204) */
+  ORC_IN_COLLISION = 1u << 2,     /* agent.in_collision             (env.py:421-424)   */
+  ORC_WAS_IN_COLLISION = 1u << 3, /* agent.was_in_collision_already (agent.py:205-206) */
+  ORC_OUT_OF_TIME = 1u << 4,      /* agent.ran_out_of_time          (agent.py:238-239) */
+  ORC_DONE = 1u << 5,             /* agent.is_done                  (env.py:534-535)   */
+  ORC_IS_LEARNING = 1u << 6,      /* policy.str == "learning"       (config.py:152-157) */
+  ORC_STILL_LEARNING = 1u << 7    /* policy.is_still_learning       (Policy.py:13)     */
+};
+/* policy ids (test_cases.py:68-85 registry) */
+enum { ORC_POL_RVO = 0, ORC_POL_NONCOOP = 1, ORC_POL_STATIC = 2, ORC_POL_EXTERNAL = 3, ORC_POL_LEARNING = 4, ORC_POL_LEARNING_GA3C = 5 };
+/* dynamics ids (test_cases.py:93-96 + UnicycleDynamicsMaxTurnRate.py) */
+enum { ORC_DYN_UNICYCLE = 0, ORC_DYN_MAX_TURN_RATE = 1, ORC_DYN_EXTERNAL = 2 };
+/* agent_sorting_method (OtherAgentsStatesSensor.py:34-52) */
+enum { ORC_SORT_CLOSEST_FIRST = 0, ORC_SORT_CLOSEST_LAST = 1, ORC_SORT_TIME_TO_IMPACT = 2 };
+/* game_over rule (env.py:537-551) */
+enum { ORC_OVER_ALL_DONE = 0 /* EVALUATE_MODE */, ORC_OVER_AGENT0 = 1 /* TRAIN_SINGLE_AGENT */, ORC_OVER_LEARNING_DONE = 2 };
+
+typedef struct {
+  int32_t num_envs, num_agents, max_obs /* K */, sort_mode, game_over_mode, rvo_max_neighbors;
+  double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
+  double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
+  double reward_min, reward_max; /* np.clip bounds, env.py:589-599 */
+  double rvo_time_horizon, rvo_collab_coeff;
+  double max_heading_change; /* env-wide pi/3, env.py:87, used by LearningPolicy.py:30 */
+} OrcParams;
+
+/* SoA state, index e*num_agents + a */
+typedef struct {
+  double *pos_x, *pos_y, *vel_x, *vel_y, *heading, *goal_x, *goal_y, *radius, *pref_speed;
+  double *time_remaining, *t, *slt /* straight_line_time_to_reach_goal */, *ep_reward;
+  float *last_action;  /* [.,2] past_actions[0] (agent.py:212-213) */
+  uint32_t *flags;
+  int32_t *policy, *dynamics, *step_num;
+  /* per env */
+  int32_t *episode_step, *reset_count;
+  double *env_stats; /* [E,8]: episodes, collision_eps, all_at_goal_eps, stuck_eps, sum steps,
+                        sum total_reward, sum time_to_goal, sum extra_time_to_goal (env_utils.py:56-87) */
+} OrcState;
+
+typedef struct {
+  double *obs;       /* [E,N,6+7K]: is_learning,num_other_agents,dist_to_goal,heading_ego_frame,pref_speed,radius,K x 7 */
+  double *rewards;   /* [E,N] */
+  uint8_t *done;     /* [E,N] which_agents_done */
+  uint8_t *game_over;/* [E] */
+  float *actions;    /* [E,N,2] the float32 all_actions array (debug / parity of the policy stage) */
+} OrcOut;
+
+int ca_oracle_version(void);
+
+/* (Re)initialise the envs with mask[e]!=0 (mask NULL = all) from cases[e][a][6] =
+ * px,py,gx,gy,pref_speed,radius (test_cases.py:545-557, EVALUATE_MODE heading = toward goal;
+ * agent.py:59-138) and write their reset observation (env.py:276-282). headings may be NULL. */
+int ca_oracle_reset(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* cases, const double* headings,
+                    const uint8_t* mask);
+
+/* One env.step for every env (no auto-reset). ext_actions [E,N,2] float64 may be NULL. */
+int ca_oracle_step(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions);
+
+/* n_steps of step + DummyVecEnv-style auto-reset (vec_env.py:120-128) from a fixture table
+ * table[n_cases][N][6]: env e's k-th reset loads case (env_id_offset + e + k*case_stride) % n_cases;
+ * episode statistics are accumulated into env_stats at each game_over. */
+int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* table, int32_t n_cases,
+                      int64_t env_id_offset, int64_t case_stride, int32_t n_steps);
+
+/* Stand-alone pieces (same arithmetic as inside step), for per-stage parity tests. */
+/* ORCA: one new velocity per agent from float inputs (rvo2 doStep for every agent of every env). */
+int ca_oracle_orca(int32_t num_envs, int32_t num_agents, const float* pos, const float* vel, const float* pref,
+                   const float* radius, const float* max_speed, float collab, float time_horizon, float time_step,
+                   int32_t max_neighbors, float neighbor_dist, float* new_vel);
+/* numpy-style round(x, 2) key used by the sensor sort (OtherAgentsStatesSensor.py:107). */
+double ca_oracle_round2(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

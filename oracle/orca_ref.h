@@ -1,0 +1,220 @@
+// oracle/orca_ref.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+//
+// CPU restatement, in C `float` arithmetic, of the ORCA velocity computation that the reference
+// reaches through `rvo2.PyRVOSimulator.doStep()` (call sites:
+// gym_collision_avoidance/envs/policies/RVOPolicy.py:25-28,46,70-74,86-90,93,96).
+//
+// PARITY UNPINNED for this file: the arithmetic lives in the third-party `mit-acl/Python-RVO2`
+// git submodule (.gitmodules:1-4; a fork of sybrenstuvel/Python-RVO2 wrapping the UNC "RVO2
+// Library" v2.0.x, C++), whose directory is EMPTY in /root/reference and whose pinned commit is
+// unknown (no .git).  There is no network, so the library cannot be fetched, and the reference's
+// tests hold no golden vector for it (tests/test_collision_avoidance.py:60-80 only checks that a
+// PNG exists).  What follows restates the published algorithm -- van den Berg, Guy, Lin, Manocha,
+// "Reciprocal n-body collision avoidance" (ORCA), and the RVO2 v2.0.x reference implementation's
+// operation order (Agent::computeNeighbors / computeNewVelocity / linearProgram1-3 / update,
+// RVO_EPSILON = 1e-5f, Vector2 division as multiply-by-reciprocal) -- as specified in
+// SURVEY.md Appendix B.  It is self-pinned: tests/golden/ records its outputs, and its behaviour
+// is anchored on the reference's own call sites (it drives the unmodified RVOPolicy.py through
+// the `rvo2` module built from oracle/rvo2_module/).
+//
+// Fork delta: `setAgentCollabCoeff` (RVOPolicy.py:86-90) replaces upstream's constant 0.5 in
+// `line.point = velocity + 0.5f * u`; with Config.RVO_COLLAB_COEFF = 0.5 (config.py:85) it is
+// identical to upstream ORCA.
+//
+// Build with -ffp-contract=off (no FMA contraction): upstream is built for baseline x86-64.
+#ifndef ORACLE_ORCA_REF_H_
+#define ORACLE_ORCA_REF_H_
+
+#include <cmath>
+#include <cstddef>
+#include <vector>
+
+namespace orca_ref {
+
+static const float kEps = 0.00001f;  // RVO_EPSILON
+
+struct Vec {
+  float x, y;
+};
+struct HalfPlane {  // an ORCA line: permitted side is to the LEFT of `dir` through `pt`
+  Vec pt, dir;
+};
+
+static inline Vec mk(float x, float y) { Vec v = {x, y}; return v; }
+static inline Vec add(Vec a, Vec b) { return mk(a.x + b.x, a.y + b.y); }
+static inline Vec sub(Vec a, Vec b) { return mk(a.x - b.x, a.y - b.y); }
+static inline Vec scl(float s, Vec a) { return mk(s * a.x, s * a.y); }   // s * v  (also v * s)
+static inline float dot(Vec a, Vec b) { return a.x * b.x + a.y * b.y; }
+static inline float cross(Vec a, Vec b) { return a.x * b.y - a.y * b.x; }  // det(a, b)
+static inline float sq(float a) { return a * a; }
+static inline float len(Vec a) { return std::sqrt(dot(a, a)); }
+// v / s is evaluated as v * (1/s) in the library's vector type.
+static inline Vec divs(Vec a, float s) { const float inv = 1.0f / s; return mk(a.x * inv, a.y * inv); }
+static inline Vec unit(Vec a) { return divs(a, len(a)); }
+
+struct Body {  // what one simulated agent carries into a step
+  Vec pos, vel, pref;
+  float radius, max_speed, collab;
+};
+
+// Neighbour list of `self`: every other agent with distSq < rangeSq, ascending by distSq,
+// insertion with strict `<` so ties keep visit (= index) order, capped at max_nb
+// (Agent::insertAgentNeighbor).  Visit order is index order, which is what the library's
+// kd-tree yields while the agent count does not exceed its leaf size (10).
+static inline void neighbours(const Body* a, size_t n, size_t self, float range_sq, size_t max_nb,
+                              std::vector<std::pair<float, size_t> >& out) {
+  out.clear();
+  if (max_nb == 0) return;
+  for (size_t j = 0; j < n; ++j) {
+    if (j == self) continue;
+    const float d2 = dot(sub(a[self].pos, a[j].pos), sub(a[self].pos, a[j].pos));
+    if (d2 < range_sq) {
+      if (out.size() < max_nb) out.push_back(std::make_pair(d2, j));
+      size_t i = out.size() - 1;
+      while (i != 0 && d2 < out[i - 1].first) {
+        out[i] = out[i - 1];
+        --i;
+      }
+      out[i] = std::make_pair(d2, j);
+      if (out.size() == max_nb) range_sq = out.back().first;
+    }
+  }
+}
+
+// The half-plane agent `me` must respect because of agent `ot` (Agent::computeNewVelocity, agent part).
+static inline HalfPlane half_plane(const Body& me, const Body& ot, float inv_horizon, float time_step) {
+  const Vec rp = sub(ot.pos, me.pos);
+  const Vec rv = sub(me.vel, ot.vel);
+  const float d2 = dot(rp, rp);
+  const float R = me.radius + ot.radius;
+  const float R2 = sq(R);
+  HalfPlane h;
+  Vec u;
+  if (d2 > R2) {
+    const Vec w = sub(rv, scl(inv_horizon, rp));
+    const float w2 = dot(w, w);
+    const float dp1 = dot(w, rp);
+    if (dp1 < 0.0f && sq(dp1) > R2 * w2) {  // closest point is on the cut-off disc
+      const float wl = std::sqrt(w2);
+      const Vec uw = divs(w, wl);
+      h.dir = mk(uw.y, -uw.x);
+      u = scl(R * inv_horizon - wl, uw);
+    } else {  // closest point is on one of the legs
+      const float leg = std::sqrt(d2 - R2);
+      if (cross(rp, w) > 0.0f) {
+        h.dir = divs(mk(rp.x * leg - rp.y * R, rp.x * R + rp.y * leg), d2);
+      } else {
+        const Vec t = divs(mk(rp.x * leg + rp.y * R, -rp.x * R + rp.y * leg), d2);
+        h.dir = mk(-t.x, -t.y);
+      }
+      const float dp2 = dot(rv, h.dir);
+      u = sub(scl(dp2, h.dir), rv);
+    }
+  } else {  // already overlapping: get out within one time step
+    const float inv_dt = 1.0f / time_step;
+    const Vec w = sub(rv, scl(inv_dt, rp));
+    const float wl = len(w);
+    const Vec uw = divs(w, wl);
+    h.dir = mk(uw.y, -uw.x);
+    u = scl(R * inv_dt - wl, uw);
+  }
+  h.pt = add(me.vel, scl(me.collab, u));
+  return h;
+}
+
+// 1-D program on line `k` subject to lines [0,k) and the speed disc (linearProgram1).
+static inline bool lp1(const std::vector<HalfPlane>& L, size_t k, float radius, Vec opt, bool dir_opt, Vec& res) {
+  const float dp = dot(L[k].pt, L[k].dir);
+  const float disc = sq(dp) + sq(radius) - dot(L[k].pt, L[k].pt);
+  if (disc < 0.0f) return false;
+  const float sd = std::sqrt(disc);
+  float t_lo = -dp - sd;
+  float t_hi = -dp + sd;
+  for (size_t i = 0; i < k; ++i) {
+    const float den = cross(L[k].dir, L[i].dir);
+    const float num = cross(L[i].dir, sub(L[k].pt, L[i].pt));
+    if (std::fabs(den) <= kEps) {
+      if (num < 0.0f) return false;
+      continue;
+    }
+    const float t = num / den;
+    if (den >= 0.0f) t_hi = std::min(t_hi, t);
+    else t_lo = std::max(t_lo, t);
+    if (t_lo > t_hi) return false;
+  }
+  if (dir_opt) {
+    if (dot(opt, L[k].dir) > 0.0f) res = add(L[k].pt, scl(t_hi, L[k].dir));
+    else res = add(L[k].pt, scl(t_lo, L[k].dir));
+  } else {
+    const float t = dot(L[k].dir, sub(opt, L[k].pt));
+    if (t < t_lo) res = add(L[k].pt, scl(t_lo, L[k].dir));
+    else if (t > t_hi) res = add(L[k].pt, scl(t_hi, L[k].dir));
+    else res = add(L[k].pt, scl(t, L[k].dir));
+  }
+  return true;
+}
+
+// 2-D program (linearProgram2): returns the index of the first line that made it infeasible, or L.size().
+static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt, bool dir_opt, Vec& res) {
+  if (dir_opt) res = scl(radius, opt);  // opt * radius (commutative per component)
+  else if (dot(opt, opt) > sq(radius)) res = scl(radius, unit(opt));
+  else res = opt;
+  for (size_t i = 0; i < L.size(); ++i) {
+    if (cross(L[i].dir, sub(L[i].pt, res)) > 0.0f) {
+      const Vec keep = res;
+      if (!lp1(L, i, radius, opt, dir_opt, res)) {
+        res = keep;
+        return i;
+      }
+    }
+  }
+  return L.size();
+}
+
+// Fallback (linearProgram3, no obstacle lines): minimise the maximum penetration.
+static inline void lp3(const std::vector<HalfPlane>& L, size_t begin, float radius, Vec& res) {
+  float depth = 0.0f;
+  std::vector<HalfPlane> P;
+  for (size_t i = begin; i < L.size(); ++i) {
+    if (cross(L[i].dir, sub(L[i].pt, res)) > depth) {
+      P.clear();
+      for (size_t j = 0; j < i; ++j) {
+        HalfPlane h;
+        const float D = cross(L[i].dir, L[j].dir);
+        if (std::fabs(D) <= kEps) {
+          if (dot(L[i].dir, L[j].dir) > 0.0f) continue;
+          h.pt = scl(0.5f, add(L[i].pt, L[j].pt));
+        } else {
+          h.pt = add(L[i].pt, scl(cross(L[j].dir, sub(L[i].pt, L[j].pt)) / D, L[i].dir));
+        }
+        h.dir = unit(sub(L[j].dir, L[i].dir));
+        P.push_back(h);
+      }
+      const Vec keep = res;
+      if (lp2(P, radius, mk(-L[i].dir.y, L[i].dir.x), true, res) < P.size()) res = keep;
+      depth = cross(L[i].dir, sub(L[i].pt, res));
+    }
+  }
+}
+
+// New velocity of agent `self` (Agent::computeNeighbors + computeNewVelocity).
+static inline Vec new_velocity(const Body* a, size_t n, size_t self, float neighbor_dist, size_t max_nb,
+                               float time_horizon, float time_step) {
+  std::vector<std::pair<float, size_t> > nb;
+  neighbours(a, n, self, sq(neighbor_dist), max_nb, nb);
+  const float inv_h = 1.0f / time_horizon;
+  std::vector<HalfPlane> L;
+  L.reserve(nb.size());
+  for (size_t i = 0; i < nb.size(); ++i) L.push_back(half_plane(a[self], a[nb[i].second], inv_h, time_step));
+  Vec v;
+  const size_t fail = lp2(L, a[self].max_speed, a[self].pref, false, v);
+  if (fail < L.size()) lp3(L, fail, a[self].max_speed, v);
+  return v;
+}
+
+// Agent::update position rule: position += newVelocity * timeStep (float).
+static inline Vec advance(Vec pos, Vec v, float time_step) { return add(pos, scl(time_step, v)); }
+
+}  // namespace orca_ref
+
+#endif  // ORACLE_ORCA_REF_H_

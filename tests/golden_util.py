@@ -1,0 +1,46 @@
+"""Helpers to read tests/golden/*.npz (recorded from the unmodified reference by oracle/gen_golden.py)."""
+import ast
+import math
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DATA = os.path.join(os.path.dirname(GOLD), "..", "gym_collision_avoidance_amd", "data")
+
+# columns of the recorded per-agent state (oracle/gen_golden.py:_snapshot)
+COLS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
+        "time_remaining", "t", "slt", "act0", "act1", "step_num")
+SCENARIOS = ("rvo10", "rvo4_swap", "rvo3", "noncoop10", "clip6_rvo", "mixed5", "train5")
+
+
+class Episode(object):
+    def __init__(self, z, c):
+        g = lambda k: z["c%d_%s" % (c, k)]
+        self.state, self.flags, self.obs = g("state"), g("flags"), g("obs")
+        self.rewards, self.done, self.game_over, self.ext = g("rewards"), g("done"), g("game_over"), g("ext")
+        self.policy, self.dynamics = g("policy"), g("dynamics")
+        self.T = self.rewards.shape[0]
+        self.N = self.state.shape[1]
+
+    def col(self, t, name):
+        return self.state[t, :, COLS.index(name)]
+
+    def case(self):
+        """[N,6] px,py,gx,gy,pref_speed,radius at t=0 and the initial headings."""
+        s = self.state[0]
+        i = COLS.index
+        return (np.stack([s[:, i("pos_x")], s[:, i("pos_y")], s[:, i("goal_x")], s[:, i("goal_y")],
+                          s[:, i("pref_speed")], s[:, i("radius")]], axis=1), s[:, i("heading")].copy())
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    meta = {k: ast.literal_eval(v.replace("inf", "math.inf")) if "inf" not in v else math.inf
+            for k, v in zip(z["meta_keys"], z["meta_vals"])}
+    eps = {int(c): Episode(z, int(c)) for c in z["cases"]}
+    return meta, eps
+
+
+def fixtures(n):
+    return np.load(os.path.join(DATA, "test_cases.npz"))["n%d" % n]
