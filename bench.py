@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/sec of the batched collision-avoidance hot path on MI355X.
+
+Metric (BASELINE.json): agent-steps/sec at 4096 envs x 10 agents, RVOPolicy (ORCA) + UnicycleDynamics +
+OtherAgentsStatesSensor (K=9, closest_first), EvaluateConfig constants (DT=0.1, MAX_TIME_RATIO=8), fixture
+cases 10_agents_500_cases with deterministic auto-reset.  One "step" = one `env.step(None)` of every env of the
+shard = one cagpu_step launch through the C ABI.  Weak scaling: every GPU owns 4096 envs (config 4 = 8 x 4096);
+the only collective is one RCCL all-reduce of the 8 episode counters.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout]
+N>1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_agent_step(K):
+    """read 44 B + write state 28 B + outputs (32 + 28 K) B = 104 + 28 K (356 B at K=9)."""
+    return 104 + 28 * K
+
+
+def cpu_baseline(n_agents, K, budget_s=12.0):
+    """The CPU oracle (oracle/ca_oracle.cpp, a single-threaded C++ restatement of the reference step: kind
+    'port') timed on this host on a bounded sample of the same workload."""
+    from oracle import ca_oracle as orc
+    table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % n_agents]
+    E = 64
+    o = orc.Oracle(orc.default_params(E, n_agents, max_obs=K))
+    o.s["policy"][:] = orc.POL_RVO
+    o.reset(table[np.arange(E) % table.shape[0]])
+    t0 = time.perf_counter()
+    o.rollout(table, 50)
+    dt = time.perf_counter() - t0
+    steps = max(50, int(budget_s / max(dt / 50, 1e-9)))
+    steps = min(steps, 200000)
+    t0 = time.perf_counter()
+    o.rollout(table, steps)
+    dt = time.perf_counter() - t0
+    return {"value": E * n_agents * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d agents x %d steps (fixture cases, auto-reset) in %.1f s; C++ oracle, 1 thread. "
+                      "The reference's own Python step measured in the build container: ~2-5 k agent-steps/s/core "
+                      "(BASELINE.md section 2)" % (E, n_agents, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--agents", type=int, default=10)
+    ap.add_argument("--mode", choices=["step", "rollout"], default="step",
+                    help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from gym_collision_avoidance_amd import _native as nat
+    from gym_collision_avoidance_amd import core
+    from gym_collision_avoidance_amd.sharding import shard_env_ids, reduce_episode_stats
+
+    N, E = a.agents, a.envs
+    K = N - 1
+    table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
+    sim = core.BatchedSim(core.make_params(E, N, max_obs=K), device=dev)
+    sim.set_plugins(nat.POL_RVO, nat.DYN_UNICYCLE)
+    off, stride = shard_env_ids(rank, world, E)
+    sim.set_fixture_table(table, env_id_offset=off, case_stride=stride)
+    sim.reset_from_table()
+
+    def run(n):
+        if a.mode == "rollout":
+            sim.rollout(n)
+        else:
+            for _ in range(n):
+                sim.step()
+
+    run(a.warmup)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()            # same stream the kernels are launched on (torch's current stream)
+    run(a.steps)
+    ev1.record()
+    stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective: 8 counters
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    if rank == 0:
+        agent_steps = float(world) * E * N * a.steps
+        value = agent_steps / wall
+        launches = 1 if a.mode == "rollout" else a.steps
+        bytes_per_launch = algorithmic_bytes_per_agent_step(K) * E * N * (a.steps / launches)
+        kern_s = gpu_ms * 1e-3 / launches          # average launch duration (HIP events over the timed region)
+        achieved = bytes_per_launch / kern_s / 1e9
+        out = {
+            "metric": "agent-steps/sec at 4096 envs x 10 agents (RVO)", "value": value, "unit": "agent-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]-shaped at the metric size: %d envs/GPU x %d agents, RVOPolicy(ORCA) + "
+                                   "UnicycleDynamics + OtherAgentsStatesSensor K=%d closest_first, DT=0.1, "
+                                   "fixture 10_agents_500_cases, auto-reset" % (E, N, K),
+                       "envs_per_gpu": E, "agents": N, "launch_mode": a.mode, "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ca_kernel<64>", "avg_launch_us": kern_s * 1e6,
+                         "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
+            "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, K)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

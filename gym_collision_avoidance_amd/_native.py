@@ -1,0 +1,88 @@
+"""ctypes binding of libcagpu.so (include/cagpu.h).  The product path: there is NO CPU fallback --
+if the HIP library is missing or fails to load this module raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcagpu.so")
+
+# ---- constants mirrored from include/cagpu.h
+CA_OK, CA_EINVAL, CA_EUNSUPPORTED, CA_ELAUNCH, CA_ENODEVICE = 0, -1, -2, -3, -4
+AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEARNING, STILL_LEARNING = (
+    1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
+POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
+POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C = range(6)
+DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
+SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
+OVER_ALL_DONE, OVER_AGENT0, OVER_LEARNING_DONE = range(3)
+
+_P = C.c_void_p
+
+
+class CaParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_agents", "max_obs", "sort_mode", "game_over_mode",
+                                         "rvo_max_neighbors")] + \
+               [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
+                                          "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
+                                          "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
+                                          "rvo_time_horizon", "rvo_collab_coeff", "max_heading_change")]
+
+
+STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
+                "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
+                "reset_count", "env_stats")
+OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions")
+
+
+class CaState(C.Structure):
+    _fields_ = [(n, _P) for n in STATE_FIELDS]
+
+
+class CaOut(C.Structure):
+    _fields_ = [(n, _P) for n in OUT_FIELDS]
+
+
+class CaAutoReset(C.Structure):
+    _fields_ = [("table", _P), ("n_cases", C.c_int32), ("env_id_offset", C.c_int64), ("case_stride", C.c_int64)]
+
+
+EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_rollout", "cagpu_orca",
+           "cagpu_observe")
+
+_lib = None
+
+
+class CagpuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcagpu.so; raise loudly if it is not there (no eager / CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CagpuError("libcagpu.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950); there is no CPU fallback for the hot path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.cagpu_version.restype = C.c_int
+    L.cagpu_last_error.restype = C.c_char_p
+    PP, PS, PO, PA = C.POINTER(CaParams), C.POINTER(CaState), C.POINTER(CaOut), C.POINTER(CaAutoReset)
+    L.cagpu_reset.argtypes = [PP, PS, PO, _P, _P, _P, _P]
+    L.cagpu_step.argtypes = [PP, PS, PO, _P, PA, _P]
+    L.cagpu_rollout.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
+    L.cagpu_observe.argtypes = [PP, PS, PO, _P]
+    L.cagpu_orca.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int32,
+                             C.c_float, _P, _P]
+    for n in EXPORTS:
+        getattr(L, n)  # AttributeError if a declared symbol is missing
+        if n not in ("cagpu_last_error",):
+            getattr(L, n).restype = C.c_int
+    L.cagpu_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CagpuError("cagpu error %d: %s" % (rc, lib().cagpu_last_error().decode()))

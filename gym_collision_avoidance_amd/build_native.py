@@ -1,0 +1,37 @@
+"""Build libcagpu.so (the HIP hot path) in-tree for gfx950.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "cagpu.hip")
+OUT = os.path.join(HERE, "libcagpu.so")
+# -ffp-contract=off: a fused multiply-add inside `dx*dx + dy*dy <= r*r` would change discrete events
+# (collision / at-goal masks) relative to the reference; see DESIGN.md "Numerics".
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared",
+         "-I" + os.path.join(REPO, "include")]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [SRC, os.path.join(REPO, "include", "cagpu.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,176 @@
+"""BatchedSim: the (num_envs x num_agents) simulator state as PyTorch-ROCm tensors + the calls into libcagpu.so.
+
+torch is plumbing here (device memory, streams); every per-step computation happens in the HIP kernels of
+csrc/cagpu.hip through the C ABI of include/cagpu.h.  Layout: agent-major SoA, index e*N + a.
+Reference objects this replaces: the list[Agent] owned by CollisionAvoidanceEnv (collision_avoidance_env.py:141,
+agent.py:29-138) and the per-step loops of collision_avoidance_env.py:156-234.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+_F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
+        "time_remaining", "t", "slt", "ep_reward")
+STAT_NAMES = ("episodes", "collision_episodes", "all_at_goal_episodes", "stuck_episodes", "sum_steps",
+              "sum_total_reward", "sum_time_to_goal", "sum_extra_time_to_goal")
+
+
+def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, sort_mode=nat.SORT_CLOSEST_FIRST,
+                game_over_mode=nat.OVER_ALL_DONE, rvo_max_neighbors=None, near_goal_threshold=0.2,
+                getting_close_range=0.2, sensing_horizon=math.inf, reward_at_goal=1.0, reward_collision=-0.25,
+                reward_time_step=0.0, reward_wiggly=0.0, wiggly_threshold=math.inf, reward_min=None, reward_max=None,
+                rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3):
+    """CaParams with the reference's Config defaults (config.py:28-86) for an EvaluateConfig-style run."""
+    p = nat.CaParams()
+    p.num_envs, p.num_agents = int(num_envs), int(num_agents)
+    p.max_obs = int(num_agents - 1 if max_obs is None else max_obs)
+    p.sort_mode, p.game_over_mode = int(sort_mode), int(game_over_mode)
+    p.rvo_max_neighbors = int(num_agents if rvo_max_neighbors is None else rvo_max_neighbors)
+    p.dt, p.near_goal_threshold, p.max_time_ratio = dt, near_goal_threshold, max_time_ratio
+    p.getting_close_range, p.sensing_horizon = getting_close_range, sensing_horizon
+    p.reward_at_goal, p.reward_collision, p.reward_time_step = reward_at_goal, reward_collision, reward_time_step
+    p.reward_wiggly, p.wiggly_threshold = reward_wiggly, wiggly_threshold
+    # collision_avoidance_env.py:589-599: clip bounds = min/max of the possible reward values
+    vals = [reward_at_goal, reward_collision, reward_time_step, reward_collision, reward_wiggly]
+    p.reward_min = min(vals) if reward_min is None else reward_min
+    p.reward_max = max(vals) if reward_max is None else reward_max
+    p.rvo_time_horizon, p.rvo_collab_coeff = rvo_time_horizon, rvo_collab_coeff
+    p.max_heading_change = max_heading_change
+    return p
+
+
+class BatchedSim(object):
+    def __init__(self, params, device="cuda:0", record_actions=False):
+        if not torch.cuda.is_available():
+            raise nat.CagpuError("BatchedSim needs a ROCm device: the hot path is HIP-only (no CPU fallback)")
+        self.lib = nat.lib()
+        self.p = params
+        self.device = torch.device(device)
+        E, N, K = params.num_envs, params.num_agents, params.max_obs
+        self.E, self.N, self.K, self.W = E, N, K, 6 + 7 * K
+        dev = self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.state = {n: z((E, N), torch.float64) for n in _F64}
+        self.state["last_action"] = z((E, N, 2), torch.float32)
+        self.state["flags"] = z((E, N), torch.int32)       # uint32 bit pattern
+        self.state["step_num"] = z((E, N), torch.int32)
+        self.state["episode_step"] = z((E,), torch.int32)
+        self.state["reset_count"] = z((E,), torch.int32)
+        self.state["env_stats"] = z((E, 8), torch.float64)
+        self.obs = z((E, N, self.W), torch.float32)
+        self.rewards = z((E, N), torch.float32)
+        self.done = z((E, N), torch.uint8)
+        self.game_over = z((E,), torch.uint8)
+        self.actions = z((E, N, 2), torch.float32) if record_actions else None
+        self._cs = nat.CaState(**{n: self.state[n].data_ptr() for n in nat.STATE_FIELDS})
+        self._co = nat.CaOut(obs=self.obs.data_ptr(), rewards=self.rewards.data_ptr(), done=self.done.data_ptr(),
+                             game_over=self.game_over.data_ptr(),
+                             actions=self.actions.data_ptr() if record_actions else None)
+        self._ar = None
+        self._table = None
+        self._keep = []
+
+    # ---------------------------------------------------------------- plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype):
+        if x is None:
+            return None
+        t = torch.as_tensor(x, dtype=dtype)
+        if t.device != self.device:
+            t = t.to(self.device)
+        return t.contiguous()
+
+    # ---------------------------------------------------------------- configuration
+    def set_plugins(self, policy, dynamics=None, is_learning=None, still_learning=None):
+        """policy / dynamics: int ids (CA_POL_*, CA_DYN_*), broadcastable to [E,N].  The learning bits default to
+        what the reference's policy classes set (LearningPolicy.py:9-11: str == 'learning', is_still_learning)."""
+        E, N = self.E, self.N
+        pol = np.broadcast_to(np.asarray(policy, np.int64), (E, N))
+        dyn = np.broadcast_to(np.asarray(0 if dynamics is None else dynamics, np.int64), (E, N))
+        learn = (pol == nat.POL_LEARNING) | (pol == nat.POL_LEARNING_GA3C)
+        isl = learn if is_learning is None else np.broadcast_to(np.asarray(is_learning, bool), (E, N))
+        stl = learn if still_learning is None else np.broadcast_to(np.asarray(still_learning, bool), (E, N))
+        bits = (pol << nat.POLICY_SHIFT) | (dyn << nat.DYNAMICS_SHIFT) | (isl * nat.IS_LEARNING) | \
+               (stl * nat.STILL_LEARNING)
+        cur = self.state["flags"]
+        cur.copy_((cur & 0x3F) | torch.as_tensor(bits.astype(np.int32), device=self.device))
+
+    def set_fixture_table(self, table, env_id_offset=0, case_stride=None):
+        """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,
+        test_cases.py:593-624): env e's k-th reset loads case (env_id_offset + e + k*case_stride) % C."""
+        if table is None:
+            self._ar, self._table = None, None
+            return
+        t = self._dev(table, torch.float64)
+        assert t.dim() == 3 and t.shape[1:] == (self.N, 6), t.shape
+        self._table = t
+        self._ar = nat.CaAutoReset(table=t.data_ptr(), n_cases=int(t.shape[0]), env_id_offset=int(env_id_offset),
+                                   case_stride=int(self.E if case_stride is None else case_stride))
+
+    # ---------------------------------------------------------------- the C-ABI calls
+    def reset(self, cases, headings=None, mask=None):
+        c = self._dev(cases, torch.float64)
+        assert tuple(c.shape) == (self.E, self.N, 6), c.shape
+        h = self._dev(headings, torch.float64)
+        m = self._dev(mask, torch.uint8)
+        nat.check(self.lib.cagpu_reset(C.byref(self.p), C.byref(self._cs), C.byref(self._co), c.data_ptr(),
+                                       None if h is None else h.data_ptr(), None if m is None else m.data_ptr(),
+                                       self._stream()))
+        self._keep = [c, h, m]  # keep alive until the stream has consumed them
+        return self.obs
+
+    def reset_from_table(self, env_id_offset=None):
+        """Initial load: env e <- case (env_id_offset + e) % C of the fixture table."""
+        assert self._table is not None
+        off = self._ar.env_id_offset if env_id_offset is None else env_id_offset
+        idx = (torch.arange(self.E, device=self.device) + off) % self._table.shape[0]
+        return self.reset(self._table[idx])
+
+    def step(self, ext_actions=None):
+        e = self._dev(ext_actions, torch.float64)
+        if e is not None:
+            assert tuple(e.shape) == (self.E, self.N, 2), e.shape
+        nat.check(self.lib.cagpu_step(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
+                                      None if e is None else e.data_ptr(),
+                                      None if self._ar is None else C.byref(self._ar), self._stream()))
+        self._keep = [e]
+        return self.obs, self.rewards, self.game_over
+
+    def rollout(self, n_steps, ext_actions=None):
+        e = self._dev(ext_actions, torch.float64)
+        nat.check(self.lib.cagpu_rollout(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
+                                         None if e is None else e.data_ptr(),
+                                         None if self._ar is None else C.byref(self._ar), int(n_steps),
+                                         self._stream()))
+        self._keep = [e]
+        return self.obs, self.rewards, self.game_over
+
+    def observe(self):
+        nat.check(self.lib.cagpu_observe(C.byref(self.p), C.byref(self._cs), C.byref(self._co), self._stream()))
+        return self.obs
+
+    # ---------------------------------------------------------------- statistics
+    def episode_stats(self):
+        """Per-shard episode counters: float64 [8] (see STAT_NAMES), reduced on the device."""
+        return self.state["env_stats"].sum(dim=0)
+
+
+def orca(pos, vel, pref, radius, max_speed, collab=0.5, time_horizon=5.0, time_step=0.1, max_neighbors=None,
+         neighbor_dist=math.inf):
+    """Batched replacement of rvo2.PyRVOSimulator.doStep() (RVOPolicy.py:93): float32 device tensors
+    pos/vel/pref [E,N,2], radius/max_speed [E,N] -> new velocities [E,N,2]."""
+    assert pos.is_cuda and pos.dtype == torch.float32
+    E, N = pos.shape[:2]
+    ts = [t.contiguous() for t in (pos, vel, pref, radius, max_speed)]
+    out = torch.empty((E, N, 2), dtype=torch.float32, device=pos.device)
+    st = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+    nat.check(nat.lib().cagpu_orca(E, N, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(),
+                                   ts[4].data_ptr(), collab, time_horizon, time_step,
+                                   N if max_neighbors is None else max_neighbors, neighbor_dist, out.data_ptr(), st))
+    return out

@@ -1,0 +1,170 @@
+/* include/cagpu.h -- C ABI of libcagpu.so, the MI355X (gfx950) hot path of the batched
+ * collision-avoidance simulator.
+ *
+ * This is the drop-in boundary.  The reference has no device boundary at
+ * all: its only FFI is the Cython `rvo2.PyRVOSimulator` binding.  Each entry point below names
+ * the reference interface it replaces (paths relative to
+ * /root/reference/gym_collision_avoidance/envs/).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types; every data pointer is a DEVICE pointer
+ *     into memory owned by the caller (torch tensors in the Python host), 16-byte aligned, valid
+ *     until the stream reaches the call.  The library never allocates or frees device memory.
+ *   - CaParams / CaState / CaOut / CaAutoReset are HOST structs, copied at call time.
+ *   - asynchronous and stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  Re-entrant across streams and devices; the only global is the
+ *     thread-local last-error string.
+ *   - returns 0 on success, a negative CA_E* code otherwise; never throws across the boundary.
+ *   - layout: agent-major SoA, index e*num_agents + a (agent fastest), one array per field, so a
+ *     wavefront's 64 lanes load 64 consecutive elements.  State is float64 because the
+ *     reference's state is (its discrete events -- at-goal, collision, time-out, sort buckets --
+ *     are decided on float64 values); observations / rewards leave as float32, the dtype the
+ *     reference declares for them (config.py:93-170).
+ */
+#ifndef CAGPU_H_
+#define CAGPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAGPU_VERSION 1
+
+/* error codes */
+enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
+
+/* per-agent flag word.  Bits 0-5 are the reference's Agent booleans (agent.py:108-112,138;
+ * env.py:421-424,534-535); bits 6-7 come from the agent's Policy object (Policy.py:11-14,
+ * config.py:152-157); bits 8-15 select the built-in policy / dynamics plugin. */
+enum {
+  CA_AT_GOAL = 1u << 0,
+  CA_WAS_AT_GOAL = 1u << 1,
+  CA_IN_COLLISION = 1u << 2,
+  CA_WAS_IN_COLLISION = 1u << 3,
+  CA_OUT_OF_TIME = 1u << 4,
+  CA_DONE = 1u << 5,
+  CA_IS_LEARNING = 1u << 6,
+  CA_STILL_LEARNING = 1u << 7,
+  CA_POLICY_SHIFT = 8,  /* 4 bits */
+  CA_DYNAMICS_SHIFT = 12 /* 4 bits */
+};
+/* policy plugin ids (test_cases.py:68-85 `policy_dict`) */
+enum {
+  CA_POL_RVO = 0,           /* policies/RVOPolicy.py + rvo2 (ORCA)           */
+  CA_POL_NONCOOP = 1,       /* policies/NonCooperativePolicy.py              */
+  CA_POL_STATIC = 2,        /* policies/StaticPolicy.py                      */
+  CA_POL_EXTERNAL = 3,      /* policies/ExternalPolicy.py: raw [speed, dheading] from ext_actions */
+  CA_POL_LEARNING = 4,      /* policies/LearningPolicy.py: scaled ext_actions */
+  CA_POL_LEARNING_GA3C = 5  /* policies/LearningPolicyGA3C.py: discrete index in ext_actions[.,0] */
+};
+/* dynamics plugin ids (test_cases.py:93-96 `dynamics_dict`) */
+enum {
+  CA_DYN_UNICYCLE = 0,      /* dynamics/UnicycleDynamics.py:14-47            */
+  CA_DYN_MAX_TURN_RATE = 1, /* dynamics/UnicycleDynamicsMaxTurnRate.py:17-43 */
+  CA_DYN_EXTERNAL = 2       /* dynamics/ExternalDynamics.py                  */
+};
+/* OtherAgentsStatesSensor.agent_sorting_method (sensors/OtherAgentsStatesSensor.py:34-52) */
+enum { CA_SORT_CLOSEST_FIRST = 0, CA_SORT_CLOSEST_LAST = 1, CA_SORT_TIME_TO_IMPACT = 2 /* not yet */ };
+/* game_over rule (collision_avoidance_env.py:537-551) */
+enum { CA_OVER_ALL_DONE = 0 /* EVALUATE_MODE */, CA_OVER_AGENT0 = 1 /* TRAIN_SINGLE_AGENT */, CA_OVER_LEARNING_DONE = 2 };
+
+/* The Config constants read on the hot path (config.py:28-86,174) + batch geometry. */
+typedef struct CaParams {
+  int32_t num_envs, num_agents;
+  int32_t max_obs;           /* K = MAX_NUM_OTHER_AGENTS_OBSERVED; obs row = 6 + 7*K floats */
+  int32_t sort_mode, game_over_mode;
+  int32_t rvo_max_neighbors; /* MAX_NUM_AGENTS_IN_ENVIRONMENT (RVOPolicy.py:15) */
+  double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
+  double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
+  double reward_min, reward_max; /* np.clip bounds (collision_avoidance_env.py:589-599) */
+  double rvo_time_horizon, rvo_collab_coeff;
+  double max_heading_change; /* env-wide pi/3 (collision_avoidance_env.py:87), LearningPolicy.py:30 */
+} CaParams;
+
+/* Device pointers to the simulator state; [E*N] unless noted. */
+typedef struct CaState {
+  double *pos_x, *pos_y;       /* Agent.pos_global_frame                       */
+  double *vel_x, *vel_y;       /* Agent.vel_global_frame                       */
+  double *heading;             /* Agent.heading_global_frame                   */
+  double *goal_x, *goal_y;     /* Agent.goal_global_frame                      */
+  double *radius, *pref_speed;
+  double *time_remaining;      /* Agent.time_remaining_to_reach_goal           */
+  double *t;                   /* Agent.t                                      */
+  double *slt;                 /* Agent.straight_line_time_to_reach_goal       */
+  double *ep_reward;           /* running sum of this episode's rewards (env_utils.py:51) */
+  float *last_action;          /* [E*N,2] Agent.past_actions[0] = [speed, delta heading] */
+  uint32_t *flags;
+  int32_t *step_num;           /* Agent.step_num                               */
+  int32_t *episode_step;       /* [E] CollisionAvoidanceEnv.episode_step_number */
+  int32_t *reset_count;        /* [E] auto-resets taken so far                 */
+  double *env_stats;           /* [E,8] episodes, collision eps, all-at-goal eps, stuck eps, sum steps,
+                                  sum total_reward, sum time_to_goal, sum extra_time_to_goal
+                                  (experiments/src/env_utils.py:56-87, reduced to counters) */
+} CaState;
+
+/* Device pointers to what a step hands back (collision_avoidance_env.py:225-234). */
+typedef struct CaOut {
+  float *obs;        /* [E,N,6+7K]: is_learning, num_other_agents, dist_to_goal, heading_ego_frame,
+                        pref_speed, radius, other_agents_states[K][7] -- the array layout of
+                        wrappers.py:143-173 (MultiagentDictToMultiagentArrayWrapper) */
+  float *rewards;    /* [E,N]                                           */
+  uint8_t *done;     /* [E,N] which_agents_done                         */
+  uint8_t *game_over;/* [E]                                             */
+  float *actions;    /* [E,N,2] the float32 `all_actions` array (env.py:305-307); may be NULL */
+} CaOut;
+
+/* Fixture-table auto-reset (the batched form of vec_env.py:120-128 + test_cases.py:593-624):
+ * when env e's episode ends its statistics are added to env_stats[e], its k-th reset loads case
+ * (env_id_offset + e + k*case_stride) % n_cases of `table` and the observation handed back is the
+ * reset observation (rewards / done / game_over stay those of the terminal step). */
+typedef struct CaAutoReset {
+  const double *table; /* device, [n_cases, N, 6] = px, py, gx, gy, pref_speed, radius */
+  int32_t n_cases;
+  int64_t env_id_offset; /* global id of this shard's env 0 (multi-GPU sharding) */
+  int64_t case_stride;   /* normally the global number of envs */
+} CaAutoReset;
+
+int cagpu_version(void);
+const char *cagpu_last_error(void);
+
+/* Replaces: Agent.reset (agent.py:59-138) for every agent of the envs with mask[e] != 0 (mask NULL =
+ * all), in the EVALUATE_MODE form of test_cases.py:545-590 (heading toward the goal unless
+ * `headings` [E,N] is given), followed by the reset observation (collision_avoidance_env.py:276-282).
+ * cases: device [E,N,6] = px, py, gx, gy, pref_speed, radius.  The policy / dynamics / learning bits
+ * of `flags` must already be set; reset_count[e] is zeroed. */
+int cagpu_reset(const CaParams *p, const CaState *s, const CaOut *o, const double *cases, const double *headings,
+                const uint8_t *mask, void *stream);
+
+/* Replaces: CollisionAvoidanceEnv.step (collision_avoidance_env.py:156-234) for every env:
+ * policy queries on the pre-step state (RVOPolicy / rvo2.doStep, NonCooperative, Static, external),
+ * Agent.take_action + UnicycleDynamics.step + update_ego_frame, _check_for_collisions,
+ * _compute_rewards, OtherAgentsStatesSensor.sense + observation assembly, _check_which_agents_done.
+ * ext_actions: device float64 [E,N,2], read only for agents with an external policy; may be NULL
+ * (the reference's `env.step(None)`, env_utils.py:50).  ar == NULL: no auto-reset. */
+int cagpu_step(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions, const CaAutoReset *ar,
+               void *stream);
+
+/* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
+ * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is
+ * needed.  This is the batched form of env_utils.py:45-52 `while not terminated: env.step(None)`.
+ * ext_actions (if any) are held constant over the n_steps. */
+int cagpu_rollout(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions,
+                  const CaAutoReset *ar, int32_t n_steps, void *stream);
+
+/* Replaces: rvo2.PyRVOSimulator.doStep() + getAgentVelocity for every agent (call sites
+ * RVOPolicy.py:25-28,70-74,86-93): one ORCA velocity per agent from C-float inputs.
+ * pos/vel/pref: device float [E,N,2]; radius/max_speed: device float [E,N]; new_vel: device float [E,N,2]. */
+int cagpu_orca(int32_t num_envs, int32_t num_agents, const float *pos, const float *vel, const float *pref,
+               const float *radius, const float *max_speed, float collab_coeff, float time_horizon, float time_step,
+               int32_t max_neighbors, float neighbor_dist, float *new_vel, void *stream);
+
+/* Replaces: OtherAgentsStatesSensor.sense + the observation assembly (OtherAgentsStatesSensor.py:58-144,
+ * agent.py:323-327) for the CURRENT state, without stepping: rewrites o->obs only. */
+int cagpu_observe(const CaParams *p, const CaState *s, const CaOut *o, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAGPU_H_ */
