@@ -8,13 +8,15 @@
 //   ego-centric sorted other-agent observation    -> OtherAgentsStatesSensor.py:58-144
 //   done / game over / fixture auto-reset + stats -> collision_avoidance_env.py:514-553, vec_env.py:120-128
 //
-// Mapping (wave64, no MFMA: this is branchy element-wise geometry): one LANE per agent, one
-// WORKGROUP per tile of WHOLE envs (tile = BLOCK / num_agents envs), so every neighbour an agent
-// needs is owned by a lane of the same workgroup and travels through LDS, never through HBM:
+// Mapping (wave64, no MFMA: this is branchy element-wise geometry): one WORKGROUP per tile of WHOLE
+// envs (floor(64 / num_agents) envs = up to 64 agents), so every neighbour an agent needs is owned by
+// the same workgroup and travels through LDS, never through HBM:
 //   * HBM loads/stores are agent-major SoA -> lane i touches element base+i: fully coalesced;
-//   * the O(N^2) pairwise passes (ORCA half-planes, collisions, sensor) read the tile's positions /
-//     velocities / radii from LDS (same-env lanes hit the same address -> broadcast);
-//   * per-lane work arrays (ORCA lines, sort keys) live in LDS as [slot][lane] columns -> bank-conflict free;
+//   * serial per-agent chains (incremental LP, float64 trig) run one LANE per agent on wave 0;
+//   * the O(N^2) pairwise work (ORCA half-planes, collision gaps, sensor keys/ranks/rows) runs one
+//     THREAD per ordered (agent, other) pair across all waves of the workgroup, reading the tile's
+//     positions / velocities / radii from LDS (same-agent threads hit the same address -> broadcast);
+//   * per-(agent, slot) work arrays live in LDS as [slot][agent] columns -> bank-conflict free;
 //   * the observation rows are staged in LDS and leave as one contiguous, coalesced block.
 // Envs never interact, so n-step rollouts need no grid-wide synchronisation.
 //
@@ -25,6 +27,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "cagpu.h"
@@ -51,6 +54,7 @@ struct KArgs {
   const double* reset_headings;
   const uint8_t* reset_mask;
   int32_t n_steps, mode, stage_obs;
+  int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
 // ---------------------------------------------------------------- small math helpers
@@ -270,19 +274,37 @@ __device__ __forceinline__ Ego ego_frame(double px, double py, double gx, double
   return e;
 }
 
-// ---------------------------------------------------------------- LDS carve-up
-// fixed part (per lane):  5 doubles (post-move pos/vel/radius) + 5 floats (ORCA bodies) + 3 doubles (stats) + 1 u32
-// union part  (per lane): max( ORCA: N floats + 2*(N-1) float4 ,  sensor: 3*N doubles + N ints [+ W floats staging] )
+// ---------------------------------------------------------------- main kernel
+// Work decomposition of one tile (ROW = 64 agent slots = floor(64/N) whole envs) on a workgroup of NT threads:
+//   agent phases  (A*): one LANE per agent, on wave 0 only -- the serial per-agent chains (incremental LP,
+//                       float64 atan2/sincos, flags).  The other waves wait at the barrier and cost no issue slots.
+//   pair phases   (P*): one THREAD per ordered (agent, other) pair, spread over all NT threads -- ORCA
+//                       neighbour distances + half-planes, collision gaps, sensor keys / ranks / row emission.
+// Everything the phases exchange lives in LDS; per-(agent, slot) arrays are [slot][ROW] columns so that a phase that
+// walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
+constexpr int ROW = 64;
+#ifdef CAGPU_ABLATE
+#define AB(bit) (k.ablate & (bit))
+__device__ unsigned long long g_prof[16];
+#define TICK(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); sh_prof[slot] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define AB(bit) false
+#define TICK(slot) do {} while (0)
+#endif
+
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
-__host__ __device__ inline size_t lds_fixed_bytes(int block) { return align16(static_cast<size_t>(block) * (8 * 8 + 5 * 4 + 4)); }
-__host__ __device__ inline size_t lds_orca_bytes(int block, int N) {
-  return align16(static_cast<size_t>(block) * N * 4) + static_cast<size_t>(block) * 2 * (N > 1 ? N - 1 : 1) * 16;
+// fixed: 10 f64 + 5 f32 + 4 u32 per agent slot
+__host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 5 * 4 + 4 * 4); }
+// union, ORCA view: dist^2 [N][ROW] f32, lines + projected lines [N-1][ROW] float4 each
+__host__ __device__ inline size_t lds_orca_bytes(int N) {
+  return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * 2 * (N > 1 ? N - 1 : 1) * 16;
 }
-__host__ __device__ inline size_t lds_sense_bytes(int block, int N, int W, int stage) {
-  return align16(static_cast<size_t>(block) * N * (3 * 8 + 4)) + (stage ? align16(static_cast<size_t>(block) * W * 4) : 0);
+// union, sensor view: key / p_orth / dist_2_other / gap [N][ROW] f64, rank [N][ROW] i32, obs staging [ROW*W] f32
+__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage) {
+  return static_cast<size_t>(ROW) * N * (4 * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
 }
 
-struct Lane {  // per-lane registers of one agent
+struct Lane {  // per-lane registers of one agent (wave 0)
   double px, py, vx, vy, heading, gx, gy, rad, ps, tr, t, slt, epr;
   float act0, act1;
   uint32_t flags;
@@ -306,53 +328,68 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ca_kernel(const KArgs k) {
+template <int NT>
+__global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
   const int N = p.num_agents, K = p.max_obs, W = 6 + 7 * K;
-  const int tile_envs = BLOCK / N;
+  const float inv_n = 1.0f / static_cast<float>(N);
+  const int tile_envs = ROW / N;
   const int tile_n = tile_envs * N;
-  const int lane = threadIdx.x;
+  const int n_items = tile_n * N;
+  const int tid = threadIdx.x;
+  const bool wave0 = tid < ROW;
+  // identity of the agent on this lane (meaningful on wave 0 only)
+  const int lane = tid & (ROW - 1);
   const int le = lane / N, a = lane - le * N;
-  const int ebase = le * N;
   const long env0 = static_cast<long>(blockIdx.x) * tile_envs;
   const long e = env0 + le;
-  const bool active = (lane < tile_n) && (e < p.num_envs);
+  const bool active = wave0 && (lane < tile_n) && (e < p.num_envs);
+  const int ebase = active ? le * N : 0;
   const long i = e * N + a;
-  const long tile_base = env0 * N;  // first global agent index of this tile
+  const long tile_base = env0 * N;
   long tile_cnt = static_cast<long>(p.num_envs) * N - tile_base;
   if (tile_cnt > tile_n) tile_cnt = tile_n;
 
   // ---- LDS
   double* sh_px = reinterpret_cast<double*>(smem);
-  double* sh_py = sh_px + BLOCK;
-  double* sh_vx = sh_py + BLOCK;
-  double* sh_vy = sh_vx + BLOCK;
-  double* sh_rad = sh_vy + BLOCK;
-  double* sh_r0 = sh_rad + BLOCK;  // stats scratch
-  double* sh_r1 = sh_r0 + BLOCK;
-  double* sh_r2 = sh_r1 + BLOCK;
-  float* sh_fpx = reinterpret_cast<float*>(sh_r2 + BLOCK);
-  float* sh_fpy = sh_fpx + BLOCK;
-  float* sh_fvx = sh_fpy + BLOCK;
-  float* sh_fvy = sh_fvx + BLOCK;
-  float* sh_frad = sh_fvy + BLOCK;
-  uint32_t* sh_flag = reinterpret_cast<uint32_t*>(sh_frad + BLOCK);
-  unsigned char* un = smem + lds_fixed_bytes(BLOCK);
+  double* sh_py = sh_px + ROW;
+  double* sh_vx = sh_py + ROW;
+  double* sh_vy = sh_vx + ROW;
+  double* sh_rad = sh_vy + ROW;
+  double* sh_prx = sh_rad + ROW;  // ego frame ref_prll (ref_orth = (-pry, prx))
+  double* sh_pry = sh_prx + ROW;
+  double* sh_r0 = sh_pry + ROW;   // episode-stat scratch
+  double* sh_r1 = sh_r0 + ROW;
+  double* sh_r2 = sh_r1 + ROW;
+  float* sh_fpx = reinterpret_cast<float*>(sh_r2 + ROW);
+  float* sh_fpy = sh_fpx + ROW;
+  float* sh_fvx = sh_fpy + ROW;
+  float* sh_fvy = sh_fvx + ROW;
+  float* sh_frad = sh_fvy + ROW;
+  uint32_t* sh_flag = reinterpret_cast<uint32_t*>(sh_frad + ROW);
+  int* sh_q = reinterpret_cast<int*>(sh_flag + ROW);  // 1: this agent queries ORCA this step
+  int* sh_nb = sh_q + ROW;                            // its neighbour count n
+  int* sh_sense = sh_nb + ROW;                        // 1: (re)write this agent's observation in this pass
+  unsigned char* un = smem + lds_fixed_bytes();
   // ORCA view of the union
-  float* dcol = reinterpret_cast<float*>(un) + lane;
-  float4* Lcol = reinterpret_cast<float4*>(un + align16(static_cast<size_t>(BLOCK) * N * 4)) + lane;
-  float4* Pcol = Lcol + static_cast<size_t>(N > 1 ? N - 1 : 1) * BLOCK;
+  float* dmat = reinterpret_cast<float*>(un);                                   // [N][ROW]
+  float4* Lmat = reinterpret_cast<float4*>(un + static_cast<size_t>(ROW) * N * 4);  // [N-1][ROW]
+  float4* Pmat = Lmat + static_cast<size_t>(N > 1 ? N - 1 : 1) * ROW;
   // sensor view of the union
-  double* kcol = reinterpret_cast<double*>(un) + lane;             // [N][BLOCK] sort key (rint(100*d))
-  double* ocol = kcol + static_cast<size_t>(N) * BLOCK;            // [N][BLOCK] p_orth
-  double* d2col = ocol + static_cast<size_t>(N) * BLOCK;           // [N][BLOCK] dist_2_other
-  int* rcol = reinterpret_cast<int*>(d2col + static_cast<size_t>(N) * BLOCK - lane) + lane;  // [N][BLOCK] rank
-  float* sh_obs = reinterpret_cast<float*>(un + align16(static_cast<size_t>(BLOCK) * N * (3 * 8 + 4)));
+  double* kmat = reinterpret_cast<double*>(un);          // [N][ROW] sort key = rint(100 * dist_2_other)
+  double* omat = kmat + static_cast<size_t>(N) * ROW;    // [N][ROW] p_orth
+  double* d2mat = omat + static_cast<size_t>(N) * ROW;   // [N][ROW] dist_2_other
+  double* gmat = d2mat + static_cast<size_t>(N) * ROW;   // [N][ROW] centre distance - combined radius
+  int* rmat = reinterpret_cast<int*>(gmat + static_cast<size_t>(N) * ROW);  // [N][ROW] rank
+  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * (4 * 8 + 4));
 
   // ---- load my agent
   Lane r;
+  r.px = r.py = r.vx = r.vy = r.heading = r.gx = r.gy = 0.0;
+  r.rad = r.ps = 1.0; r.tr = r.t = r.slt = r.epr = 0.0;
+  r.act0 = r.act1 = 0.f; r.flags = CA_DONE | CA_AT_GOAL; r.step_num = 0;
+  int ep_step = 0, reset_cnt = 0;
   if (active) {
     r.px = k.s.pos_x[i]; r.py = k.s.pos_y[i]; r.vx = k.s.vel_x[i]; r.vy = k.s.vel_y[i];
     r.heading = k.s.heading[i]; r.gx = k.s.goal_x[i]; r.gy = k.s.goal_y[i];
@@ -362,17 +399,12 @@ __global__ __launch_bounds__(BLOCK) void ca_kernel(const KArgs k) {
     r.act0 = la.x; r.act1 = la.y;
     r.flags = k.s.flags[i];
     r.step_num = k.s.step_num[i];
-  } else {
-    r.px = r.py = r.vx = r.vy = r.heading = r.gx = r.gy = 0.0;
-    r.rad = r.ps = 1.0; r.tr = r.t = r.slt = r.epr = 0.0;
-    r.act0 = r.act1 = 0.f; r.flags = CA_DONE | CA_AT_GOAL; r.step_num = 0;
+    ep_step = k.s.episode_step[e];
+    reset_cnt = k.s.reset_count[e];
   }
-  int ep_step = 0, reset_cnt = 0;
-  if (active) { ep_step = k.s.episode_step[e]; reset_cnt = k.s.reset_count[e]; }
-
-  bool do_sense = true;   // does my env need its observation (re)written
+  bool statics_dirty = false;  // goal / radius / pref_speed / slt changed (reset, StaticPolicy)
+  bool do_sense = active;
   float reward = 0.f;
-  uint32_t done_out = 0, over_out = 0;
 
   if (k.mode == MODE_RESET) {
     do_sense = active && (!k.reset_mask || k.reset_mask[e]);
@@ -380,318 +412,440 @@ __global__ __launch_bounds__(BLOCK) void ca_kernel(const KArgs k) {
       reset_lane(r, k.reset_cases + i * 6, k.reset_headings ? k.reset_headings + i : nullptr, p);
       ep_step = 0;
       reset_cnt = 0;
+      statics_dirty = true;
     }
   }
 
+#ifdef CAGPU_ABLATE
+  __shared__ unsigned long long sh_prof[16];
+  if (tid < 16) sh_prof[tid] = 0;
+  __syncthreads();
+  unsigned long long tprev_ = clock64();
+#endif
   const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
   for (int step = 0; step < n_steps; ++step) {
+    TICK(0);
     if (k.mode == MODE_STEP) {
-      ep_step += 1;  // env.py:183
-      // ================= 1. policy: actions from the PRE-step state (env.py:305-323)
-      sh_fpx[lane] = static_cast<float>(r.px);
-      sh_fpy[lane] = static_cast<float>(r.py);
-      sh_fvx[lane] = static_cast<float>(r.vx);
-      sh_fvy[lane] = static_cast<float>(r.vy);
-      sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
-      __syncthreads();
-      double spd = 0.0, dh = 0.0;
+      // ================= A1: who queries ORCA, float bodies (RVOPolicy.py:57-74)
       const uint32_t pol = (r.flags >> CA_POLICY_SHIFT) & 0xF;
-      if (active && !(r.flags & CA_DONE)) {  // env.py:311
-        if (pol == CA_POL_RVO) {
-          const double vx = r.gx - r.px, vy = r.gy - r.py;
-          const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
-          const F2 pref = f2(static_cast<float>(sc * vx), static_cast<float>(sc * vy));
-          const float ts = static_cast<float>(p.dt);
-          const F2 v = orca_velocity<BLOCK>(sh_fpx, sh_fpy, sh_fvx, sh_fvy, sh_frad, ebase, a, N, pref,
-                                            static_cast<float>(r.ps), static_cast<float>(p.rvo_collab_coeff),
-                                            static_cast<float>(p.rvo_time_horizon), ts,
-                                            static_cast<float>(p.sensing_horizon), p.rvo_max_neighbors, dcol, Lcol, Pcol);
-          // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
-          const float npx = sh_fpx[lane] + v.x * ts, npy = sh_fpy[lane] + v.y * ts;
-          const double dpx = static_cast<double>(npx) - r.px, dpy = static_cast<double>(npy) - r.py;
-          const double ang = atan2(dpy, dpx);
-          const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
-          dh = wrap_pi(nh - r.heading);
-          spd = (1.0 / p.dt) * sqrt(dpx * dpx + dpy * dpy);
-          if (fabs(dh) > kPi / 6) {
-            dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
-            spd = 0.0;
+      const bool query = active && !(r.flags & CA_DONE);  // env.py:311
+      const bool rvo = query && pol == CA_POL_RVO;
+      if (wave0) {
+        ep_step += 1;  // env.py:183
+        sh_fpx[lane] = static_cast<float>(r.px);
+        sh_fpy[lane] = static_cast<float>(r.py);
+        sh_fvx[lane] = static_cast<float>(r.vx);
+        sh_fvy[lane] = static_cast<float>(r.vy);
+        sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
+        sh_q[lane] = rvo ? 1 : 0;
+      }
+      const int any_rvo = __syncthreads_or(rvo ? 1 : 0);
+      TICK(1);
+      if (any_rvo && !AB(1)) {
+        // ================= P1: squared centre distances of every (agent, other) pair (Agent::insertAgentNeighbor)
+        const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
+        for (int w = tid; w < n_items; w += NT) {
+          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+          const int j = w - ag * N;
+          if (!sh_q[ag]) continue;
+          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+          float d2 = INFINITY;
+          if (j != aa) {
+            const F2 d = f2(sh_fpx[ag], sh_fpy[ag]) - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
+            d2 = dotf(d, d);
+            if (!(d2 < range_sq)) d2 = INFINITY;
           }
-        } else if (pol == CA_POL_NONCOOP) {  // NonCooperativePolicy.py:21
-          const Ego eg = ego_frame(r.px, r.py, r.gx, r.gy, r.heading);
-          spd = r.ps;
-          dh = -eg.heading_ego;
-        } else if (pol == CA_POL_STATIC) {  // StaticPolicy.py:21-23
-          r.gx = r.px;
-          r.gy = r.py;
-        } else if (k.ext) {
-          const double e0 = k.ext[2 * i], e1 = k.ext[2 * i + 1];
-          if (pol == CA_POL_EXTERNAL) {  // ExternalPolicy.py:14-16
-            spd = e0;
-            dh = e1;
-          } else if (pol == CA_POL_LEARNING) {  // LearningPolicy.py:29-33
-            dh = p.max_heading_change * (2. * e1 - 1.);
-            spd = r.ps * e0;
-          } else if (pol == CA_POL_LEARNING_GA3C) {  // LearningPolicyGA3C.py:24-26, network.py:7-16
-            int q = static_cast<int>(e0);
-            q = q < 0 ? 0 : (q > 10 ? 10 : q);
-            const double s0 = (q < 5) ? 1.0 : ((q < 8) ? 0.5 : 0.0);
-            const double h5[5] = {-kPi / 6, -kPi / 12, 0.0, kPi / 12, kPi / 6};
-            const double h3[3] = {-kPi / 6, 0.0, kPi / 6};
-            spd = r.ps * s0;
-            dh = (q < 5) ? h5[q] : h3[(q - 5) % 3];
+          dmat[j * ROW + ag] = d2;
+        }
+        __syncthreads();
+        // ================= P2: neighbour rank (ascending distSq, ties by index) + ORCA half-plane
+        const float inv_h = divf(1.0f, static_cast<float>(p.rvo_time_horizon));
+        const float ts = static_cast<float>(p.dt);
+        const float collab = static_cast<float>(p.rvo_collab_coeff);
+        for (int w = tid; w < n_items; w += NT) {
+          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+          const int j = w - ag * N;
+          if (!sh_q[ag]) continue;
+          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+          const float dj = dmat[j * ROW + ag];
+          int rank = 0, cnt = 0;
+          for (int q = 0; q < N; ++q) {
+            const float dq = dmat[q * ROW + ag];
+            rank += (dq < dj) || (dq == dj && q < j);
+            cnt += (dq < INFINITY);
+          }
+          const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
+          if (j == aa) {
+            sh_nb[ag] = n;
+          } else if (dj < INFINITY && rank < n) {
+            Lmat[rank * ROW + ag] = half_plane(f2(sh_fpx[ag], sh_fpy[ag]), f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
+                                               f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
+                                               sh_frad[eb + j], collab, inv_h, ts);
           }
         }
+        __syncthreads();
       }
-      const float a0f = static_cast<float>(spd), a1f = static_cast<float>(dh);  // float32 `all_actions`
-      if (active && k.o.actions) reinterpret_cast<float2*>(k.o.actions)[i] = make_float2(a0f, a1f);
 
-      // ================= 2. move (agent.py:192-241)
-      if (active) {
-        if (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) {
-          if (r.flags & CA_AT_GOAL) r.flags |= CA_WAS_AT_GOAL;
-          if (r.flags & CA_IN_COLLISION) r.flags |= CA_WAS_IN_COLLISION;
-          r.vx = r.vy = 0.0;
-        } else {
-          r.act0 = a0f;
-          r.act1 = a1f;
-          const double a0 = a0f, a1 = a1f;
-          const uint32_t dyn = (r.flags >> CA_DYNAMICS_SHIFT) & 0xF;
-          if (dyn != CA_DYN_EXTERNAL) {
-            double nh;
-            if (dyn == CA_DYN_MAX_TURN_RATE) {  // UnicycleDynamicsMaxTurnRate.py:31-33
-              double trn = a1 / p.dt;
-              trn = fmin(fmax(trn, -3.0), 3.0);
-              nh = wrap_pi(trn * p.dt + r.heading);
-            } else {
-              nh = wrap_pi(a1 + r.heading);  // UnicycleDynamics.py:28
+      TICK(2);
+      // ================= A2: policy (env.py:305-323) and move (agent.py:192-241), one lane per agent
+      if (wave0) {
+        double spd = 0.0, dh = 0.0;
+        if (query) {
+          if (pol == CA_POL_RVO) {
+            const double vx = r.gx - r.px, vy = r.gy - r.py;
+            const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
+            const F2 pref = f2(static_cast<float>(sc * vx), static_cast<float>(sc * vy));
+            const float ts = static_cast<float>(p.dt);
+            const float ms = static_cast<float>(r.ps);
+            const int n = sh_nb[lane];
+            F2 v;
+            int fail = n;
+            if (AB(2)) v = pref; else fail = lp2<ROW>(Lmat + lane, n, ms, pref, false, v);
+            if (fail < n) lp3<ROW>(Lmat + lane, Pmat + lane, n, fail, ms, v);
+            TICK(3);
+            // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
+            const float npx = sh_fpx[lane] + v.x * ts, npy = sh_fpy[lane] + v.y * ts;
+            const double dpx = static_cast<double>(npx) - r.px, dpy = static_cast<double>(npy) - r.py;
+            const double ang = AB(4) ? dpy : atan2(dpy, dpx);
+            const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
+            dh = wrap_pi(nh - r.heading);
+            spd = (1.0 / p.dt) * sqrt(dpx * dpx + dpy * dpy);
+            if (fabs(dh) > kPi / 6) {
+              dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
+              spd = 0.0;
             }
-            double sn, cs;
-            sincos(nh, &sn, &cs);
-            r.px += a0 * cs * p.dt;
-            r.py += a0 * sn * p.dt;
-            r.vx = a0 * cs;
-            r.vy = a0 * sn;
-            r.heading = nh;
+          } else if (pol == CA_POL_NONCOOP) {  // NonCooperativePolicy.py:21
+            const Ego eg = ego_frame(r.px, r.py, r.gx, r.gy, r.heading);
+            spd = r.ps;
+            dh = -eg.heading_ego;
+          } else if (pol == CA_POL_STATIC) {  // StaticPolicy.py:21-23
+            r.gx = r.px;
+            r.gy = r.py;
+            statics_dirty = true;
+          } else if (k.ext) {
+            const double e0 = k.ext[2 * i], e1 = k.ext[2 * i + 1];
+            if (pol == CA_POL_EXTERNAL) {  // ExternalPolicy.py:14-16
+              spd = e0;
+              dh = e1;
+            } else if (pol == CA_POL_LEARNING) {  // LearningPolicy.py:29-33
+              dh = p.max_heading_change * (2. * e1 - 1.);
+              spd = r.ps * e0;
+            } else if (pol == CA_POL_LEARNING_GA3C) {  // LearningPolicyGA3C.py:24-26, network.py:7-16
+              int q = static_cast<int>(e0);
+              q = q < 0 ? 0 : (q > 10 ? 10 : q);
+              const int hq = (q < 5) ? q - 2 : ((q - 5) % 3 - 1) * 2;  // heading index in units of pi/12
+              const double s0 = (q < 5) ? 1.0 : ((q < 8) ? 0.5 : 0.0);
+              spd = r.ps * s0;
+              dh = (hq == -2) ? -kPi / 6 : (hq == -1) ? -kPi / 12 : (hq == 0) ? 0.0 : (hq == 1) ? kPi / 12 : kPi / 6;
+            }
           }
-          const double qx = r.px - r.gx, qy = r.py - r.gy;
-          if (qx * qx + qy * qy <= p.near_goal_threshold * p.near_goal_threshold) r.flags |= CA_AT_GOAL;
-          else r.flags &= ~static_cast<uint32_t>(CA_AT_GOAL);
-          r.tr -= p.dt;
-          r.t += p.dt;
-          r.step_num += 1;
-          if (r.tr <= 0.0) r.flags |= CA_OUT_OF_TIME;
+        }
+        TICK(4);
+        const float a0f = static_cast<float>(spd), a1f = static_cast<float>(dh);  // float32 `all_actions`
+        if (active && k.o.actions) reinterpret_cast<float2*>(k.o.actions)[i] = make_float2(a0f, a1f);
+        if (active) {
+          if (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) {
+            if (r.flags & CA_AT_GOAL) r.flags |= CA_WAS_AT_GOAL;
+            if (r.flags & CA_IN_COLLISION) r.flags |= CA_WAS_IN_COLLISION;
+            r.vx = r.vy = 0.0;
+          } else {
+            r.act0 = a0f;
+            r.act1 = a1f;
+            const double a0 = a0f, a1 = a1f;
+            const uint32_t dyn = (r.flags >> CA_DYNAMICS_SHIFT) & 0xF;
+            if (dyn != CA_DYN_EXTERNAL) {
+              double nh;
+              if (dyn == CA_DYN_MAX_TURN_RATE) {  // UnicycleDynamicsMaxTurnRate.py:31-33
+                double trn = a1 / p.dt;
+                trn = fmin(fmax(trn, -3.0), 3.0);
+                nh = wrap_pi(trn * p.dt + r.heading);
+              } else {
+                nh = wrap_pi(a1 + r.heading);  // UnicycleDynamics.py:28
+              }
+              double sn, cs;
+              if (AB(8)) { sn = nh; cs = 1.0 - nh; } else sincos(nh, &sn, &cs);
+              r.px += a0 * cs * p.dt;
+              r.py += a0 * sn * p.dt;
+              r.vx = a0 * cs;
+              r.vy = a0 * sn;
+              r.heading = nh;
+            }
+            const double qx = r.px - r.gx, qy = r.py - r.gy;
+            if (qx * qx + qy * qy <= p.near_goal_threshold * p.near_goal_threshold) r.flags |= CA_AT_GOAL;
+            else r.flags &= ~static_cast<uint32_t>(CA_AT_GOAL);
+            r.tr -= p.dt;
+            r.t += p.dt;
+            r.step_num += 1;
+            if (r.tr <= 0.0) r.flags |= CA_OUT_OF_TIME;
+          }
         }
       }
-      __syncthreads();  // everyone is done with the ORCA view of the union
+      do_sense = active;
+      TICK(5);
     }
 
-    // ================= 3-6 run once, and a second time for envs that auto-reset this step
+    // ================= sensing passes: once, and a second time for envs that auto-reset in this step
     for (int pass = 0; pass < 2; ++pass) {
-      // publish the post-move tile
-      sh_px[lane] = r.px; sh_py[lane] = r.py; sh_vx[lane] = r.vx; sh_vy[lane] = r.vy; sh_rad[lane] = r.rad;
+      // ---- A: publish the post-move tile + ego frames (agent.py:329-349, Dynamics.py:24-41)
+      Ego eg;
+      eg.dist = 0.0; eg.prx = eg.pry = eg.orx = eg.ory = eg.heading_ego = 0.0;
+      if (wave0) {
+        sh_px[lane] = r.px; sh_py[lane] = r.py; sh_vx[lane] = r.vx; sh_vy[lane] = r.vy; sh_rad[lane] = r.rad;
+        if (do_sense) {
+          if (AB(16)) { eg.dist = r.px; eg.prx = 1.0; eg.pry = 0.0; eg.heading_ego = r.heading; } else eg = ego_frame(r.px, r.py, r.gx, r.gy, r.heading);
+          sh_prx[lane] = eg.prx;
+          sh_pry[lane] = eg.pry;
+        }
+        sh_sense[lane] = do_sense ? 1 : 0;
+      }
+      __syncthreads();
+      TICK(6);
+
+      // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
+      //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
+      for (int w = tid; w < n_items && !AB(32); w += NT) {
+        const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+        const int j = w - ag * N;
+        if (!sh_sense[ag]) continue;
+        const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+        double key = INFINITY, po = 0.0, d2o = 0.0, gap = INFINITY;
+        if (j != aa) {
+          const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag];
+          const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
+          const double rx = ox - hx, ry = oy - hy;
+          const double d = sqrt(rx * rx + ry * ry);
+          gap = d - (hr + orad);
+          if (!(d > p.sensing_horizon)) {
+            d2o = d - hr - orad;
+            key = rint(d2o * 100.0);  // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100
+            po = rx * (-sh_pry[ag]) + ry * sh_prx[ag];
+          }
+        }
+        kmat[j * ROW + ag] = key;
+        omat[j * ROW + ag] = po;
+        d2mat[j * ROW + ag] = d2o;
+        gmat[j * ROW + ag] = gap;
+      }
       __syncthreads();
 
-      // ---- pairwise pass: collisions + nearest (env.py:458-512) and sensor candidates (sensor :76-107)
-      Ego eg;
-      int cnt = 0;
-      bool coll = false;
-      double nearest = INFINITY;
-      if (active && do_sense) {
-        eg = ego_frame(r.px, r.py, r.gx, r.gy, r.heading);
-        for (int j = 0; j < N; ++j) {
-          double key = INFINITY, po = 0.0, d2o = 0.0;
-          if (j != a) {
-            const double ox = sh_px[ebase + j], oy = sh_py[ebase + j], orad = sh_rad[ebase + j];
-            const double rx = ox - r.px, ry = oy - r.py;
-            const double d = sqrt(rx * rx + ry * ry);
-            const double cr = r.rad + orad;
-            const double gap = d - cr;
-            nearest = (gap < nearest) ? gap : nearest;
-            coll = coll || (d <= cr);
-            if (!(d > p.sensing_horizon)) {
-              d2o = d - r.rad - orad;
-              key = rint(d2o * 100.0);  // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100
-              po = rx * eg.orx + ry * eg.ory;
-              ++cnt;
+      TICK(7);
+      // ---- A3 (wave 0): rewards + collision flag (env.py:394-456), observation scalars
+      if (wave0 && active) {
+        if (k.mode == MODE_STEP && pass == 0) {
+          double nearest = INFINITY;
+          for (int j = 0; j < N; ++j) {
+            const double g = gmat[j * ROW + lane];
+            nearest = (g < nearest) ? g : nearest;
+          }
+          const bool coll = nearest <= 0.0;  // some d <= r_i + r_j  <=>  min(d - (r_i + r_j)) <= 0
+          double rw = p.reward_time_step;
+          if (r.flags & CA_AT_GOAL) {
+            if (!(r.flags & CA_WAS_AT_GOAL)) rw = p.reward_at_goal;
+          } else if (!(r.flags & CA_WAS_IN_COLLISION)) {
+            if (coll) {
+              rw = p.reward_collision;
+              r.flags |= CA_IN_COLLISION;
+            } else {
+              if (nearest <= p.getting_close_range) rw = -0.1 - nearest / 2.0;
+              if (fabs(static_cast<double>(r.act1)) > p.wiggly_threshold) rw += p.reward_wiggly;
             }
           }
-          kcol[j * BLOCK] = key;
-          ocol[j * BLOCK] = po;
-          d2col[j * BLOCK] = d2o;
+          rw = fmin(fmax(rw, p.reward_min), p.reward_max);
+          r.epr += rw;
+          reward = static_cast<float>(rw);
+          const bool d = (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) != 0;
+          if (d) r.flags |= CA_DONE; else r.flags &= ~static_cast<uint32_t>(CA_DONE);
+          sh_flag[lane] = r.flags;
+          sh_r0[lane] = r.epr;
+          sh_r1[lane] = r.t;
+          sh_r2[lane] = r.t - r.slt;
+        }
+        if (do_sense) {
+          float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
+          row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
+          row[2] = static_cast<float>(eg.dist);
+          row[3] = static_cast<float>(eg.heading_ego);
+          row[4] = static_cast<float>(r.ps);
+          row[5] = static_cast<float>(r.rad);
         }
       }
 
-      // ---- rewards + collision flag (env.py:394-456); only on the stepping pass
-      if (k.mode == MODE_STEP && pass == 0 && active) {
-        double rw = p.reward_time_step;
-        if (r.flags & CA_AT_GOAL) {
-          if (!(r.flags & CA_WAS_AT_GOAL)) rw = p.reward_at_goal;
-        } else if (!(r.flags & CA_WAS_IN_COLLISION)) {
-          if (coll) {
-            rw = p.reward_collision;
-            r.flags |= CA_IN_COLLISION;
-          } else {
-            if (nearest <= p.getting_close_range) rw = -0.1 - nearest / 2.0;
-            if (fabs(static_cast<double>(r.act1)) > p.wiggly_threshold) rw += p.reward_wiggly;
-          }
+      TICK(8);
+      // ---- P4: rank the candidates of every agent and emit its rows (OtherAgentsStatesSensor.py:20-55,109-143)
+      for (int w = tid; w < n_items && !AB(64); w += NT) {
+        const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+        const int j = w - ag * N;
+        if (!sh_sense[ag]) continue;
+        const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+        const double kj = kmat[j * ROW + ag], oj = omat[j * ROW + ag];
+        int rank = 0, cnt = 0;
+        for (int q = 0; q < N; ++q) {
+          const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+          rank += (kq < kj) || (kq == kj && (oq < oj || (oq == oj && q < j)));
+          cnt += (kq < INFINITY);
         }
-        rw = fmin(fmax(rw, p.reward_min), p.reward_max);
-        r.epr += rw;
-        reward = static_cast<float>(rw);
-      }
-
-      // ---- sensor: rank the candidates, emit rows (sensor :20-55,:109-143)
-      if (active && do_sense) {
         const int keep = cnt < K ? cnt : K;
-        float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
-        row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
-        row[1] = static_cast<float>(keep);
-        row[2] = static_cast<float>(eg.dist);
-        row[3] = static_cast<float>(eg.heading_ego);
-        row[4] = static_cast<float>(r.ps);
-        row[5] = static_cast<float>(r.rad);
-        for (int q = 6 + 7 * keep; q < W; ++q) row[q] = 0.f;
-        for (int j = 0; j < N; ++j) {
-          const double kj = kcol[j * BLOCK];
-          int rank = N;
-          if (kj < INFINITY) {
-            const double oj = ocol[j * BLOCK];
-            rank = 0;
-            for (int q = 0; q < N; ++q) {
-              const double kq = kcol[q * BLOCK], oq = ocol[q * BLOCK];
-              rank += (kq < kj) || (kq == kj && (oq < oj || (oq == oj && q < j)));
-            }
+        float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+        if (j == aa) row[1] = static_cast<float>(keep);  // num_other_agents_observed
+        for (int sl = j; sl < K; sl += N)                // zero the unfilled rows (sensor :112)
+          if (sl >= keep) {
+            float* z = row + 6 + 7 * sl;
+            z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = z[6] = 0.f;
           }
-          rcol[j * BLOCK] = rank;
+        const bool kept = (j != aa) && (kj < INFINITY) && (rank < keep);
+        if (p.sort_mode == CA_SORT_CLOSEST_LAST) {
+          rmat[j * ROW + ag] = kept ? rank : N;
+          continue;
         }
-        for (int j = 0; j < N; ++j) {
-          int rank = rcol[j * BLOCK];
-          if (rank >= keep) continue;
-          if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable
-            const double kj = kcol[j * BLOCK], oj = ocol[j * BLOCK];
-            int r2 = 0;
-            for (int q = 0; q < N; ++q) {
-              const int rq = rcol[q * BLOCK];
-              if (rq >= keep) continue;
-              const double kq = kcol[q * BLOCK], oq = ocol[q * BLOCK];
-              r2 += (kq > kj) || (kq == kj && (oq < oj || (oq == oj && rq < rank)));
-            }
-            rank = r2;
+        if (!kept) continue;
+        const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
+        const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
+        const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
+        const double rx = ox - hx, ry = oy - hy;
+        float* o7 = row + 6 + 7 * rank;
+        o7[0] = static_cast<float>(rx * prx + ry * pry);
+        o7[1] = static_cast<float>(rx * (-pry) + ry * prx);
+        o7[2] = static_cast<float>(ovx * prx + ovy * pry);
+        o7[3] = static_cast<float>(ovx * (-pry) + ovy * prx);
+        o7[4] = static_cast<float>(orad);
+        o7[5] = static_cast<float>(hr + orad);
+        o7[6] = static_cast<float>(d2mat[j * ROW + ag]);
+      }
+      if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
+        __syncthreads();
+        for (int w = tid; w < n_items; w += NT) {
+          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+          const int j = w - ag * N;
+          if (!sh_sense[ag]) continue;
+          const int rank = rmat[j * ROW + ag];
+          if (rank >= N) continue;
+          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N;
+          const double kj = kmat[j * ROW + ag], oj = omat[j * ROW + ag];
+          int r2 = 0;
+          for (int q = 0; q < N; ++q) {
+            const int rq = rmat[q * ROW + ag];
+            if (rq >= N) continue;
+            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+            r2 += (kq > kj) || (kq == kj && (oq < oj || (oq == oj && rq < rank)));
           }
-          const double ox = sh_px[ebase + j], oy = sh_py[ebase + j], orad = sh_rad[ebase + j];
-          const double ovx = sh_vx[ebase + j], ovy = sh_vy[ebase + j];
-          const double rx = ox - r.px, ry = oy - r.py;
-          float* o7 = row + 6 + 7 * rank;
-          o7[0] = static_cast<float>(rx * eg.prx + ry * eg.pry);
-          o7[1] = static_cast<float>(rx * eg.orx + ry * eg.ory);
-          o7[2] = static_cast<float>(ovx * eg.prx + ovy * eg.pry);
-          o7[3] = static_cast<float>(ovx * eg.orx + ovy * eg.ory);
+          float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+          const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
+          const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
+          const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
+          const double rx = ox - hx, ry = oy - hy;
+          float* o7 = row + 6 + 7 * r2;
+          o7[0] = static_cast<float>(rx * prx + ry * pry);
+          o7[1] = static_cast<float>(rx * (-pry) + ry * prx);
+          o7[2] = static_cast<float>(ovx * prx + ovy * pry);
+          o7[3] = static_cast<float>(ovx * (-pry) + ovy * prx);
           o7[4] = static_cast<float>(orad);
-          o7[5] = static_cast<float>(r.rad + orad);
-          o7[6] = static_cast<float>(d2col[j * BLOCK]);
+          o7[5] = static_cast<float>(hr + orad);
+          o7[6] = static_cast<float>(d2mat[j * ROW + ag]);
         }
       }
+      __syncthreads();
 
-      // ---- done / game over (env.py:514-553); only on the stepping pass
+      TICK(9);
+      // ---- A4 (wave 0): done / game over (env.py:514-553), auto-reset (vec_env.py:120-128), episode statistics
       bool need_second = false;
       if (k.mode == MODE_STEP && pass == 0) {
-        const bool d = (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) != 0;
-        if (d) r.flags |= CA_DONE; else r.flags &= ~static_cast<uint32_t>(CA_DONE);
-        done_out = d;
-        sh_flag[lane] = r.flags;
-        sh_r0[lane] = r.epr;
-        sh_r1[lane] = r.t;
-        sh_r2[lane] = r.t - r.slt;
-        __syncthreads();
-        bool all_done = true, all_learning_done = true, any_coll = false, all_goal = true;
-        for (int j = 0; j < N; ++j) {
-          const uint32_t f = sh_flag[ebase + j];
-          const bool dj = (f & CA_DONE) != 0;
-          all_done = all_done && dj;
-          if (f & CA_STILL_LEARNING) all_learning_done = all_learning_done && dj;
-          any_coll = any_coll || (f & CA_IN_COLLISION);
-          all_goal = all_goal && (f & CA_AT_GOAL);
-        }
-        bool over = all_done;
-        if (p.game_over_mode == CA_OVER_AGENT0) over = (sh_flag[ebase] & CA_DONE) != 0;
-        else if (p.game_over_mode == CA_OVER_LEARNING_DONE) over = all_learning_done;
-        over_out = over;
-        // per-step outputs that are final regardless of auto-reset
-        if (active) {
-          k.o.rewards[i] = reward;
-          k.o.done[i] = static_cast<uint8_t>(done_out);
-          if (a == 0) k.o.game_over[e] = static_cast<uint8_t>(over_out);
-        }
-        // auto-reset (vec_env.py:120-128) + episode statistics (env_utils.py:56-87)
         do_sense = false;
-        if (active && over && k.table) {
-          if (a == 0) {
-            double tot_r = 0.0, ttg = 0.0, extra = 0.0;
-            for (int j = 0; j < N; ++j) {
-              tot_r += sh_r0[ebase + j];
-              ttg += sh_r1[ebase + j];
-              extra += sh_r2[ebase + j];
-            }
-            double* st = k.s.env_stats + 8 * e;
-            st[0] += 1.0;
-            if (any_coll) st[1] += 1.0;
-            else if (all_goal) st[2] += 1.0;
-            else st[3] += 1.0;
-            st[4] += ep_step;
-            st[5] += tot_r;
-            st[6] += ttg;
-            st[7] += extra;
+        if (wave0 && active) {
+          bool all_done = true, all_learning_done = true, any_coll = false, all_goal = true;
+          for (int j = 0; j < N; ++j) {
+            const uint32_t f = sh_flag[ebase + j];
+            const bool dj = (f & CA_DONE) != 0;
+            all_done = all_done && dj;
+            if (f & CA_STILL_LEARNING) all_learning_done = all_learning_done && dj;
+            any_coll = any_coll || (f & CA_IN_COLLISION);
+            all_goal = all_goal && (f & CA_AT_GOAL);
           }
-          reset_cnt += 1;
-          const long c = (k.env_id_offset + e + static_cast<long>(reset_cnt) * k.case_stride) % k.n_cases;
-          reset_lane(r, k.table + (c * N + a) * 6, nullptr, p);
-          ep_step = 0;
-          do_sense = true;
-          need_second = true;
+          bool over = all_done;
+          if (p.game_over_mode == CA_OVER_AGENT0) over = (sh_flag[ebase] & CA_DONE) != 0;
+          else if (p.game_over_mode == CA_OVER_LEARNING_DONE) over = all_learning_done;
+          k.o.rewards[i] = reward;
+          k.o.done[i] = static_cast<uint8_t>((r.flags & CA_DONE) != 0);
+          if (a == 0) k.o.game_over[e] = static_cast<uint8_t>(over);
+          if (over && k.table) {
+            if (a == 0) {  // experiments/src/env_utils.py:56-87 reduced to counters, summed in agent order
+              double tot_r = 0.0, ttg = 0.0, extra = 0.0;
+              for (int j = 0; j < N; ++j) {
+                tot_r += sh_r0[ebase + j];
+                ttg += sh_r1[ebase + j];
+                extra += sh_r2[ebase + j];
+              }
+              double* st = k.s.env_stats + 8 * e;
+              st[0] += 1.0;
+              if (any_coll) st[1] += 1.0;
+              else if (all_goal) st[2] += 1.0;
+              else st[3] += 1.0;
+              st[4] += ep_step;
+              st[5] += tot_r;
+              st[6] += ttg;
+              st[7] += extra;
+            }
+            reset_cnt += 1;
+            const long c = (k.env_id_offset + e + static_cast<long>(reset_cnt) * k.case_stride) % k.n_cases;
+            reset_lane(r, k.table + (c * N + a) * 6, nullptr, p);
+            ep_step = 0;
+            statics_dirty = true;
+            do_sense = true;
+            need_second = true;
+          }
         }
       }
-      // ---- write the observation block of this tile (coalesced from the LDS staging area)
       const int again = __syncthreads_or(need_second ? 1 : 0);
+      TICK(10);
       if (!again) {
-        if (k.stage_obs) {
-          // NOTE: in MODE_RESET with a mask, rows of unmasked envs were not staged: copy per env.
+        // ---- the tile's observation block leaves LDS as one contiguous, coalesced copy
+        if (k.stage_obs && !AB(128)) {
           const long total = tile_cnt * W;
           float* dst = k.o.obs + tile_base * W;
           if (k.mode == MODE_RESET && k.reset_mask) {
-            for (long q = lane; q < total; q += BLOCK) {
-              const long ag = q / W;  // agent within tile
-              const long ee = env0 + ag / N;
+            for (long q = tid; q < total; q += NT) {
+              const long ee = env0 + (q / W) / N;
               if (k.reset_mask[ee]) dst[q] = sh_obs[q];
             }
           } else if (((tile_base * W) & 3) == 0 && (total & 3) == 0) {
             const float4* src4 = reinterpret_cast<const float4*>(sh_obs);
             float4* dst4 = reinterpret_cast<float4*>(dst);
-            for (long q = lane; q < (total >> 2); q += BLOCK) dst4[q] = src4[q];
+            for (long q = tid; q < (total >> 2); q += NT) dst4[q] = src4[q];
           } else {
-            for (long q = lane; q < total; q += BLOCK) dst[q] = sh_obs[q];
+            for (long q = tid; q < total; q += NT) dst[q] = sh_obs[q];
           }
         }
         break;
       }
-      // some env in this tile was reset: stage everything written so far stays; redo sensing for reset envs
-      // (rows of non-reset envs are already in the staging area / in HBM)
     }
-    __syncthreads();  // staging area free again before the next step's ORCA view
-    do_sense = true;
+    __syncthreads();  // the union is free again before the next step's ORCA view
+    TICK(11);
   }
 
-  // ---- store my agent
+#ifdef CAGPU_ABLATE
+  __syncthreads();
+  if (tid < 16) atomicAdd(&g_prof[tid], sh_prof[tid]);
+#endif
+  // ---- store my agent.  The pointers are re-read from the kernarg segment here (laundered so the compiler does
+  // not keep 19 pointer pairs alive in SGPRs across the whole kernel).
   if (active && k.mode != MODE_OBSERVE && (k.mode == MODE_STEP || !k.reset_mask || k.reset_mask[e])) {
-    k.s.pos_x[i] = r.px; k.s.pos_y[i] = r.py; k.s.vel_x[i] = r.vx; k.s.vel_y[i] = r.vy;
-    k.s.heading[i] = r.heading; k.s.time_remaining[i] = r.tr; k.s.t[i] = r.t;
-    k.s.ep_reward[i] = r.epr;
-    k.s.goal_x[i] = r.gx; k.s.goal_y[i] = r.gy;
-    k.s.radius[i] = r.rad; k.s.pref_speed[i] = r.ps; k.s.slt[i] = r.slt;
-    reinterpret_cast<float2*>(k.s.last_action)[i] = make_float2(r.act0, r.act1);
-    k.s.flags[i] = r.flags;
-    k.s.step_num[i] = r.step_num;
-    if (a == 0) { k.s.episode_step[e] = ep_step; k.s.reset_count[e] = reset_cnt; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const KArgs ConstKArgs;
+    ConstKArgs* ka = (ConstKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+#else
+    const KArgs* ka = &k;
+#endif
+    ka->s.pos_x[i] = r.px; ka->s.pos_y[i] = r.py; ka->s.vel_x[i] = r.vx; ka->s.vel_y[i] = r.vy;
+    ka->s.heading[i] = r.heading; ka->s.time_remaining[i] = r.tr; ka->s.t[i] = r.t;
+    ka->s.ep_reward[i] = r.epr;
+    if (statics_dirty) {
+      ka->s.goal_x[i] = r.gx; ka->s.goal_y[i] = r.gy;
+      ka->s.radius[i] = r.rad; ka->s.pref_speed[i] = r.ps; ka->s.slt[i] = r.slt;
+    }
+    reinterpret_cast<float2*>(ka->s.last_action)[i] = make_float2(r.act0, r.act1);
+    ka->s.flags[i] = r.flags;
+    ka->s.step_num[i] = r.step_num;
+    if (a == 0) { ka->s.episode_step[e] = ep_step; ka->s.reset_count[e] = reset_cnt; }
   }
 }
 
@@ -718,9 +872,9 @@ __global__ __launch_bounds__(BLOCK) void orca_kernel(const OrcaArgs k) {
   float* sh_fvx = sh_fpy + BLOCK;
   float* sh_fvy = sh_fvx + BLOCK;
   float* sh_frad = sh_fvy + BLOCK;
-  unsigned char* un = smem + align16(static_cast<size_t>(BLOCK) * 5 * 4);
+  unsigned char* un = smem + static_cast<size_t>(BLOCK) * 5 * 4;
   float* dcol = reinterpret_cast<float*>(un) + lane;
-  float4* Lcol = reinterpret_cast<float4*>(un + align16(static_cast<size_t>(BLOCK) * N * 4)) + lane;
+  float4* Lcol = reinterpret_cast<float4*>(un + static_cast<size_t>(BLOCK) * N * 4) + lane;
   float4* Pcol = Lcol + static_cast<size_t>(N > 1 ? N - 1 : 1) * BLOCK;
   F2 pref = f2(0.f, 0.f);
   float ms = 0.f;
@@ -766,48 +920,55 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-int pick_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : 256); }
-
-template <int BLOCK>
+template <int NT>
 int launch_main(const KArgs& k, hipStream_t st) {
   const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
   KArgs kk = k;
-  size_t un_orca = lds_orca_bytes(BLOCK, N);
-  size_t un_sense = lds_sense_bytes(BLOCK, N, W, 1);
+  const size_t un_orca = lds_orca_bytes(N);
+  size_t un_sense = lds_sense_bytes(N, W, 1);
   kk.stage_obs = 1;
-  size_t total = lds_fixed_bytes(BLOCK) + (un_orca > un_sense ? un_orca : un_sense);
-  if (total > 64 * 1024) {  // keep >= 2 workgroups per CU: give up the staging area first
-    un_sense = lds_sense_bytes(BLOCK, N, W, 0);
+  size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
+  if (total > 64 * 1024) {  // keep >= 2 workgroups per CU when possible: give up the staging area first
+    un_sense = lds_sense_bytes(N, W, 0);
     kk.stage_obs = 0;
-    total = lds_fixed_bytes(BLOCK) + (un_orca > un_sense ? un_orca : un_sense);
+    total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<BLOCK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int tile_envs = BLOCK / N;
+  const int tile_envs = ROW / N;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL(ca_kernel<BLOCK>, dim3(grid), dim3(BLOCK), total, st, kk);
+  hipLaunchKernelGGL(ca_kernel<NT>, dim3(grid), dim3(NT), total, st, kk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }
 
+// Workgroup size.  Measured on MI355X at 4096 envs x 10 agents (profiles/r01_kernel_geometry.md): 128 threads
+// (wave 0 = agent lanes, wave 1 helps with the pair phases) gives 40.7 us/step in a fused rollout, 256 -> 57,
+// 512 -> 72: the kernel needs ~225 VGPRs, so only 8 waves fit a CU and larger workgroups stop being co-resident
+// (683 workgroups then run in ~3 rounds).  CAGPU_NT overrides for experiments.
 int launch_any(const KArgs& k, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (pick_block(k.p.num_agents)) {
-    case 64: return launch_main<64>(k, st);
-    case 128: return launch_main<128>(k, st);
-    default: return launch_main<256>(k, st);
-  }
+  const int N = k.p.num_agents;
+  const int items = (ROW / N) * N * N;
+  (void)items;
+  int nt = 128;
+  if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
+  if (nt <= 128) return launch_main<128>(k, st);
+  if (nt <= 256) return launch_main<256>(k, st);
+  return launch_main<512>(k, st);
 }
+
+int pick_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : 256); }
 
 template <int BLOCK>
 int launch_orca(const OrcaArgs& k, hipStream_t st) {
   const int N = k.num_agents;
-  const size_t total = align16(static_cast<size_t>(BLOCK) * 5 * 4) + lds_orca_bytes(BLOCK, N);
+  const size_t total = static_cast<size_t>(BLOCK) * (5 * 4 + N * 4 + 2 * (N > 1 ? N - 1 : 1) * 16);
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
   if (total > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&orca_kernel<BLOCK>),
@@ -856,6 +1017,9 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
     k.table = ar->table; k.n_cases = ar->n_cases; k.env_id_offset = ar->env_id_offset; k.case_stride = ar->case_stride;
   }
   k.n_steps = n_steps; k.mode = MODE_STEP;
+#ifdef CAGPU_ABLATE
+  if (const char* ab = std::getenv("CAGPU_ABLATE")) k.ablate = std::atoi(ab);
+#endif
   return launch_any(k, stream);
 }
 
@@ -878,6 +1042,15 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
   k.n_steps = 1; k.mode = MODE_OBSERVE;
   return launch_any(k, stream);
 }
+
+#ifdef CAGPU_ABLATE
+int cagpu_debug_prof(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 int cagpu_orca(int32_t num_envs, int32_t num_agents, const float* pos, const float* vel, const float* pref,
                const float* radius, const float* max_speed, float collab_coeff, float time_horizon, float time_step,
