@@ -21,7 +21,7 @@ _P = C.c_void_p
 
 class CaParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_agents", "max_obs", "sort_mode", "game_over_mode",
-                                         "rvo_max_neighbors")] + \
+                                         "rvo_max_neighbors", "obs_clip", "reserved0")] + \
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",

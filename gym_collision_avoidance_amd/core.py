@@ -23,11 +23,12 @@ def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, 
                 game_over_mode=nat.OVER_ALL_DONE, rvo_max_neighbors=None, near_goal_threshold=0.2,
                 getting_close_range=0.2, sensing_horizon=math.inf, reward_at_goal=1.0, reward_collision=-0.25,
                 reward_time_step=0.0, reward_wiggly=0.0, wiggly_threshold=math.inf, reward_min=None, reward_max=None,
-                rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3):
+                rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3, obs_clip=None):
     """CaParams with the reference's Config defaults (config.py:28-86) for an EvaluateConfig-style run."""
     p = nat.CaParams()
     p.num_envs, p.num_agents = int(num_envs), int(num_agents)
     p.max_obs = int(num_agents - 1 if max_obs is None else max_obs)
+    p.obs_clip = p.max_obs if obs_clip is None else int(obs_clip)
     p.sort_mode, p.game_over_mode = int(sort_mode), int(game_over_mode)
     p.rvo_max_neighbors = int(num_agents if rvo_max_neighbors is None else rvo_max_neighbors)
     p.dt, p.near_goal_threshold, p.max_time_ratio = dt, near_goal_threshold, max_time_ratio

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           rank += (kq < kj) || (kq == kj && (oq < oj || (oq == oj && q < j)));
           cnt += (kq < INFINITY);
         }
-        const int keep = cnt < K ? cnt : K;
+        const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
         float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
         if (j == aa) row[1] = static_cast<float>(keep);  // num_other_agents_observed
         for (int sl = j; sl < K; sl += N)                // zero the unfilled rows (sensor :112)
@@ -907,6 +907,7 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   if (p->num_envs < 1 || p->num_agents < 1) return fail(CA_EINVAL, "cagpu: num_envs and num_agents must be >= 1%s");
   if (p->num_agents > 64) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 64 not supported yet (ORCA line tile must fit the 160 KiB LDS)%s");
   if (p->max_obs < 0) return fail(CA_EINVAL, "cagpu: max_obs < 0%s");
+  if (p->obs_clip < 0 || p->obs_clip > p->max_obs) return fail(CA_EINVAL, "cagpu: obs_clip must be in [0, max_obs]%s");
   if (p->sort_mode != CA_SORT_CLOSEST_FIRST && p->sort_mode != CA_SORT_CLOSEST_LAST)
     return fail(CA_EUNSUPPORTED, "cagpu: only closest_first / closest_last sorting is implemented%s");
   if (p->game_over_mode < 0 || p->game_over_mode > 2) return fail(CA_EINVAL, "cagpu: bad game_over_mode%s");

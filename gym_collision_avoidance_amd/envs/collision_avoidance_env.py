@@ -1,0 +1,387 @@
+"""CollisionAvoidanceEnv: drop-in for the reference's gym.Env (gym_collision_avoidance/envs/collision_avoidance_env.py)
+backed by the batched HIP simulator.
+
+    env = CollisionAvoidanceEnv()                 # num_envs = 1: the reference's behaviour and return types
+    env.set_agents(agents); obs, _ = env.reset()
+    obs, rewards, game_over, truncated, info = env.step({0: np.array([1.0, 0.5])})
+
+    venv = CollisionAvoidanceEnv(num_envs=4096)   # batched: tensors on the device, auto-reset from a fixture table
+    venv.set_fixture_suite(10, "RVO"); obs = venv.reset()[0]     # obs: float32 [E, N, 6+7K]
+    obs, rewards, game_over, _, info = venv.step(None)
+
+Everything `step` computes (policy queries, dynamics, collisions, rewards, sensors, done flags; reference lines
+156-234, 284-327, 394-575) happens in ONE launch of the fused kernel (csrc/cagpu.hip).  The host only translates the
+reference's call conventions: the actions dict, the nested observation dict, the info dicts keyed by agent.id.
+Out of scope here: plotting / animation, static maps and map-based sensors.
+"""
+import copy
+import inspect
+
+import numpy as np
+
+from gym_collision_avoidance_amd import _native as nat
+from gym_collision_avoidance_amd.envs import Config
+from gym_collision_avoidance_amd.envs import test_cases as tc
+from gym_collision_avoidance_amd.envs.policies import (ExternalPolicy, InternalPolicy, LearningPolicy,
+                                                       LearningPolicyGA3C, NonCooperativePolicy, RVOPolicy,
+                                                       StaticPolicy)
+from gym_collision_avoidance_amd.envs.spaces import Box, Dict, Env
+
+_BUILTIN_POLICIES = (RVOPolicy, NonCooperativePolicy, StaticPolicy, ExternalPolicy, LearningPolicy, LearningPolicyGA3C)
+_SORT = {"closest_first": nat.SORT_CLOSEST_FIRST, "closest_last": nat.SORT_CLOSEST_LAST,
+         "time_to_impact": nat.SORT_TIME_TO_IMPACT}
+_F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed", "time_remaining",
+        "t", "slt", "ep_reward")
+
+
+class CollisionAvoidanceEnv(Env):
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
+
+    def __init__(self, num_envs=1, device="cuda:0"):
+        self.id = 0
+        self.num_envs = int(num_envs)
+        self.device = device
+        self._initialize_rewards()
+        self.num_agents = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
+        self.dt_nominal = Config.DT
+        self.collision_dist = Config.COLLISION_DIST
+        self.getting_close_range = Config.GETTING_CLOSE_RANGE
+        self.evaluate = Config.EVALUATE_MODE
+        self.plot_episodes = False  # plotting is host-side tooling, out of scope
+        self.test_case_index = 0
+        self.set_testcase(Config.TEST_CASE_FN, dict(Config.TEST_CASE_ARGS))
+        # action bounds (collision_avoidance_env.py:86-109)
+        self.max_heading_change = np.pi / 3
+        self.min_heading_change = -self.max_heading_change
+        self.min_speed, self.max_speed = 0.0, 1.0
+        self.low_action = np.array([self.min_speed, self.min_heading_change])
+        self.high_action = np.array([self.max_speed, self.max_heading_change])
+        self.action_space = Box(self.low_action, self.high_action, dtype=np.float32)
+        # Dict[agent -> Dict[state -> Box]] observation space + zero observation (:116-139)
+        self.observation = {}
+        self.observation_space = Dict({})
+        for slot in range(Config.MAX_NUM_AGENTS_IN_ENVIRONMENT):
+            self.observation[slot] = self._zero_obs()
+            self.observation_space.spaces[slot] = Dict({
+                s: Box(Config.STATE_INFO_DICT[s]["bounds"][0] * np.ones(Config.STATE_INFO_DICT[s]["size"]),
+                       Config.STATE_INFO_DICT[s]["bounds"][1] * np.ones(Config.STATE_INFO_DICT[s]["size"]),
+                       dtype=Config.STATE_INFO_DICT[s]["dtype"]) for s in Config.STATES_IN_OBS})
+        self.agents = None
+        self.default_agents = None
+        self.prev_episode_agents = None
+        self.static_map_filename = None
+        self.map = None
+        self.episode_step_number = None
+        self.episode_number = 0
+        self.plot_save_dir = None
+        self.plot_policy_name = None
+        self.perturbed_obs = None
+        self._sim = None
+        self._sim_key = None
+        self._snap = None
+        self._obs_np = None
+        self._fixture = None
+        self._all_agents = None
+
+    # ------------------------------------------------------------------ configuration (reference setters)
+    def set_agents(self, agents):
+        """list[Agent] (used for every env) or, in batched mode, a list of num_envs such lists
+        (collision_avoidance_env.py:335-343)."""
+        self.default_agents = agents
+        self._fixture = None
+
+    def set_fixture_suite(self, num_agents, policies="RVO", agents_dynamics="unicycle", auto_reset=True,
+                          env_id_offset=0, case_stride=None):
+        """Batched evaluation on the reference's 500-case suite (run_full_test_suite.py:54-130): env e starts on case
+        (env_id_offset + e) % 500 and, with auto_reset, its k-th episode loads case (env_id_offset + e + k*stride) % 500
+        on the device (DummyVecEnv semantics, vec_env.py:120-128)."""
+        table = tc.fixture_table(num_agents)
+        self._fixture = dict(table=table, policies=policies, dynamics=agents_dynamics, auto_reset=auto_reset,
+                             env_id_offset=env_id_offset,
+                             case_stride=self.num_envs if case_stride is None else case_stride)
+        self.default_agents = None
+
+    def set_static_map(self, map_filename):
+        raise NotImplementedError("static maps / map sensors are a 'next' row (SURVEY.md section 8f)")
+
+    def set_plot_save_dir(self, plot_save_dir):
+        self.plot_save_dir = plot_save_dir  # accepted and ignored: no plotting here
+
+    def set_perturbed_info(self, perturbed_obs):
+        self.perturbed_obs = perturbed_obs
+
+    def set_testcase(self, test_case_fn_str, test_case_args):
+        """Function of test_cases.py called by reset() when no agents were set (:615-642)."""
+        fn = getattr(tc, test_case_fn_str, None)
+        assert callable(fn), "no test case function %r" % test_case_fn_str
+        accepted = inspect.signature(fn).parameters
+        self.test_case_fn = fn
+        self.test_case_args = {k: v for k, v in test_case_args.items() if k in accepted}
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self):
+        """-> (observation, {}) (:236-282)."""
+        if self.evaluate and self.agents is not None:
+            self.prev_episode_agents = copy.deepcopy(self.agents)
+        if self.episode_step_number is not None and self.episode_step_number > 0:
+            self.episode_number += 1
+        self.episode_step_number = 0
+        per_env = self._init_agents()
+        self._upload(per_env)
+        for slot in range(Config.MAX_NUM_AGENTS_IN_ENVIRONMENT):
+            self.observation[slot] = self._zero_obs()
+        return self._get_obs(), {}
+
+    def step(self, actions, dt=None):
+        """-> (next_observations, rewards, game_over, False, info) (:156-234).  `actions`: dict {agent index: action}
+        for agents with an external policy (may be None / {} when every policy is internal), or, batched, an array
+        [E, N, 2]."""
+        if self._sim is None:
+            raise RuntimeError("call reset() before step()")
+        sim = self._sim
+        sim.p.dt = self.dt_nominal if dt is None else float(dt)
+        self.episode_step_number += 1
+        ext = self._external_actions(actions)
+        sim.step(ext)
+        self._snap, self._obs_np = None, None
+        if Config.STORE_HISTORY and self.num_envs == 1:
+            self._record_history()
+        if self.num_envs > 1:
+            info = {"which_agents_done": sim.done.bool(),
+                    "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
+            return sim.obs, sim.rewards, sim.game_over.bool(), False, info
+        rewards = sim.rewards[0].double().cpu().numpy()
+        done = sim.done[0].cpu().numpy().astype(bool)
+        game_over = bool(sim.game_over[0].item())
+        if Config.TRAIN_SINGLE_AGENT:
+            rewards = rewards[0]
+        info = {"which_agents_done": {a.id: bool(done[i]) for i, a in enumerate(self.agents)},
+                "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
+        return self._get_obs(), rewards, game_over, False, info
+
+    # ------------------------------------------------------------------ internals
+    def _init_agents(self):
+        """-> list (per env) of list[Agent] (:345-367)."""
+        E = self.num_envs
+        if self._fixture is not None:
+            f = self._fixture
+            per_env = None  # built on the device from the table; only env 0 gets Agent views
+            idx = (f["env_id_offset"] + 0) % len(f["table"])
+            self.agents = tc.cadrl_test_case_to_agents(f["table"][idx], policies=f["policies"],
+                                                       agents_dynamics=f["dynamics"])
+        else:
+            if self.default_agents is None:
+                agents = self.test_case_fn(**self.test_case_args)
+            else:
+                agents = self.default_agents
+            if len(agents) and isinstance(agents[0], (list, tuple)):
+                assert len(agents) == E, "need one agent list per env"
+                per_env = [list(a) for a in agents]
+            else:
+                per_env = [list(agents)] + [None] * (E - 1)
+            self.agents = per_env[0]
+        for group in ([self.agents] if per_env is None else [g for g in per_env if g is not None]):
+            for agent in group:
+                agent.max_heading_change = self.max_heading_change
+                agent.max_speed = self.max_speed
+        return per_env
+
+    def _plugin_ids(self, agents):
+        pol, dyn, isl, stl = [], [], [], []
+        self._host_policies = []
+        for i, a in enumerate(agents):
+            p = a.policy
+            if type(p) in _BUILTIN_POLICIES:
+                pol.append(p.kernel_id)
+            else:  # user plugin: queried on the host, handed to the kernel as a raw command
+                pol.append(nat.POL_EXTERNAL)
+                self._host_policies.append(i)
+            if a.dynamics_model.kernel_id is None:
+                raise NotImplementedError("custom Dynamics subclasses are not supported (the move happens in the "
+                                          "kernel): use Unicycle / MaxTurnRate / External")
+            dyn.append(a.dynamics_model.kernel_id)
+            isl.append(p.str == "learning")
+            stl.append(bool(p.is_still_learning))
+        return pol, dyn, isl, stl
+
+    def _sensor_args(self, agents):
+        K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
+        clip, sort = K, Config.AGENT_SORTING_METHOD
+        found = set()
+        for a in agents:
+            for s in a.sensors:
+                if getattr(s, "name", None) == "other_agents_states":
+                    found.add((min(int(s.max_num_other_agents_observed), K), s.agent_sorting_method))
+        if len(found) > 1:
+            raise NotImplementedError("per-agent sensor arguments must agree across agents: %s" % sorted(found))
+        if found:
+            clip, sort = found.pop()
+        if sort not in _SORT:
+            raise ValueError("unknown agent_sorting_method %r" % sort)
+        return K, clip, _SORT[sort]
+
+    def _upload(self, per_env):
+        import torch
+        from gym_collision_avoidance_amd import core
+        E = self.num_envs
+        agents0 = self.agents
+        N = len(agents0)
+        K, clip, sort = self._sensor_args(agents0)
+        over = (nat.OVER_ALL_DONE if Config.EVALUATE_MODE else
+                nat.OVER_AGENT0 if Config.TRAIN_SINGLE_AGENT else nat.OVER_LEARNING_DONE)
+        key = (E, N, K)
+        if self._sim is None or self._sim_key != key:
+            params = core.make_params(E, N, max_obs=K)
+            self._sim = core.BatchedSim(params, device=self.device)
+            self._sim_key = key
+        sim, p = self._sim, self._sim.p
+        p.obs_clip, p.sort_mode, p.game_over_mode = clip, sort, over
+        p.rvo_max_neighbors = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
+        p.dt, p.near_goal_threshold, p.max_time_ratio = Config.DT, Config.NEAR_GOAL_THRESHOLD, Config.MAX_TIME_RATIO
+        p.getting_close_range, p.sensing_horizon = Config.GETTING_CLOSE_RANGE, Config.SENSING_HORIZON
+        p.reward_at_goal, p.reward_collision = self.reward_at_goal, self.reward_collision_with_agent
+        p.reward_time_step, p.reward_wiggly = self.reward_time_step, self.reward_wiggly_behavior
+        p.wiggly_threshold = self.wiggly_behavior_threshold
+        p.reward_min, p.reward_max = self.min_possible_reward, self.max_possible_reward
+        p.rvo_time_horizon, p.rvo_collab_coeff = Config.RVO_TIME_HORIZON, Config.RVO_COLLAB_COEFF
+        p.max_heading_change = self.max_heading_change
+        if self._fixture is not None:
+            f = self._fixture
+            pol, dyn, isl, stl = self._plugin_ids(agents0)
+            sim.set_plugins(np.array(pol)[None], np.array(dyn)[None], np.array(isl)[None], np.array(stl)[None])
+            sim.set_fixture_table(f["table"] if f["auto_reset"] else None, env_id_offset=f["env_id_offset"],
+                                  case_stride=f["case_stride"])
+            idx = (np.arange(E) + f["env_id_offset"]) % len(f["table"])
+            sim.reset(f["table"][idx])
+            groups = [agents0]
+        else:
+            sim.set_fixture_table(None)
+            groups = [g if g is not None else agents0 for g in per_env]
+            if any(len(g) != N for g in groups):
+                raise NotImplementedError("every env of a batch must hold the same number of agents")
+            ids = [self._plugin_ids(g) for g in groups]
+            self._plugin_ids(agents0)  # leaves self._host_policies describing env 0
+            sim.set_plugins(*[np.array([x[k] for x in ids]) for k in range(4)])
+            rows = [[a._case_row() for a in g] for g in groups]
+            cases = np.array([[r[0] for r in g] for g in rows], dtype=np.float64)
+            heads = np.array([[r[1] for r in g] for g in rows], dtype=np.float64)
+            sim.reset(cases, headings=heads)
+        if self._host_policies and E > 1:
+            raise NotImplementedError("user-defined Python policies are a single-env convenience path")
+        for e, g in enumerate(groups if self._fixture is None else [agents0]):
+            if per_env is None or per_env[e] is not None or e == 0:
+                for a_idx, agent in enumerate(g):
+                    agent._bind(self, e, a_idx)
+        self._snap, self._obs_np = None, None
+        if Config.STORE_HISTORY and E == 1:
+            self._record_history(initial=True)
+
+    def _external_actions(self, actions):
+        """reference actions dict / batched array -> float64 [E, N, 2] (or None when nobody needs one)."""
+        E, N = self.num_envs, len(self.agents)
+        if actions is not None and not isinstance(actions, dict):
+            return actions  # already [E, N, 2]
+        need = [i for i, a in enumerate(self.agents) if a.policy.is_external] + list(self._host_policies)
+        if not need:
+            return None
+        ext = np.zeros((E, N, 2), dtype=np.float64)
+        actions = actions or {}
+        for i, agent in enumerate(self.agents):
+            if i in self._host_policies:
+                if agent.is_done:  # collision_avoidance_env.py:311
+                    continue
+                p = agent.policy
+                if isinstance(p, ExternalPolicy):
+                    ext[0, i] = np.asarray(p.external_action_to_action(agent, actions[i]), dtype=np.float64)
+                elif isinstance(p, InternalPolicy):
+                    ext[0, i] = np.asarray(p.find_next_action(self.observation[i], self.agents, i), dtype=np.float64)
+            elif agent.policy.is_external and i in actions:
+                a = np.asarray(actions[i], dtype=np.float64)
+                if a.ndim == 0:          # LearningPolicyGA3C: a discrete index
+                    ext[:, i, 0] = a
+                else:
+                    ext[:, i, :a.shape[-1]] = a
+        return ext
+
+    def _snapshot(self):
+        """host copy of the device state, refreshed at most once per step"""
+        if self._snap is None:
+            st = self._sim.state
+            snap = {n: st[n].cpu().numpy() for n in _F64 + ("flags", "step_num", "last_action")}
+            self._snap = snap
+        return self._snap
+
+    def _obs_host(self):
+        if self._obs_np is None:
+            self._obs_np = self._sim.obs.cpu().numpy()
+        return self._obs_np
+
+    def _write_agent(self, e, a, **fields):
+        for name, v in fields.items():
+            self._sim.state[name][e, a] = float(v)
+        self._snap = None
+
+    def _zero_obs(self):
+        return {s: np.zeros(Config.STATE_INFO_DICT[s]["size"], dtype=Config.STATE_INFO_DICT[s]["dtype"])
+                for s in Config.STATES_IN_OBS}
+
+    def _get_obs(self):
+        """Batched: the device tensor [E, N, 6+7K].  Single env: the reference's nested dict
+        {agent index: {state: array}} (:555-575); slots beyond the agents in the scene keep their zeros."""
+        if self.num_envs > 1:
+            return self._sim.obs
+        row = self._obs_host()[0]
+        K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
+        cols = {"is_learning": 0, "num_other_agents": 1, "dist_to_goal": 2, "heading_ego_frame": 3, "pref_speed": 4,
+                "radius": 5}
+        for i in range(len(self.agents)):
+            obs = {}
+            for s in Config.STATES_IN_OBS:
+                if s == "other_agents_states":
+                    obs[s] = row[i, 6:6 + 7 * K].astype(np.float64).reshape(K, 7)
+                elif s == "other_agent_states":
+                    obs[s] = row[i, 6:13].astype(np.float64)
+                elif s == "is_learning":
+                    obs[s] = np.array(bool(row[i, 0]))
+                elif s == "num_other_agents":
+                    obs[s] = np.array(int(row[i, 1]))
+                elif s in cols:
+                    obs[s] = np.array(np.float64(row[i, cols[s]]))
+                else:
+                    raise NotImplementedError("state %r is not produced by the batched simulator" % s)
+            self.observation[i] = obs
+        return self.observation
+
+    def _record_history(self, initial=False):
+        """Config.STORE_HISTORY: append [t, px, py, gx, gy, radius, pref_speed, vx, vy, speed, heading] for agents
+        that moved this step (agent.py:257-289)."""
+        if initial:
+            return
+        for a in self.agents:
+            if len(a._history) < a.step_num:
+                g, _ = a.to_vector()
+                g[0] = a.t - self.dt_nominal  # the reference logs t before incrementing it (agent.py:227-236)
+                a._history.append(g)
+
+    def _initialize_rewards(self):
+        self.reward_at_goal = Config.REWARD_AT_GOAL
+        self.reward_collision_with_agent = Config.REWARD_COLLISION_WITH_AGENT
+        self.reward_collision_with_wall = Config.REWARD_COLLISION_WITH_WALL
+        self.reward_getting_close = Config.REWARD_GETTING_CLOSE
+        self.reward_entered_norm_zone = Config.REWARD_ENTERED_NORM_ZONE
+        self.reward_time_step = Config.REWARD_TIME_STEP
+        self.reward_wiggly_behavior = Config.REWARD_WIGGLY_BEHAVIOR
+        self.wiggly_behavior_threshold = Config.WIGGLY_BEHAVIOR_THRESHOLD
+        self.possible_reward_values = np.array([self.reward_at_goal, self.reward_collision_with_agent,
+                                                self.reward_time_step, self.reward_collision_with_wall,
+                                                self.reward_wiggly_behavior])
+        self.min_possible_reward = float(np.min(self.possible_reward_values))
+        self.max_possible_reward = float(np.max(self.possible_reward_values))
+
+    # ------------------------------------------------------------------ batched extras
+    def episode_stats(self):
+        """{name: value} of the episode counters accumulated on the device (core.STAT_NAMES), this shard only;
+        reduce across GPUs with sharding.reduce_episode_stats."""
+        from gym_collision_avoidance_amd import core
+        vals = self._sim.episode_stats().cpu().numpy()
+        return dict(zip(core.STAT_NAMES, [float(v) for v in vals]))

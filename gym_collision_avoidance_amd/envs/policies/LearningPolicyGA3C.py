@@ -1,0 +1,28 @@
+import numpy as np
+
+from gym_collision_avoidance_amd import _native as nat
+from .LearningPolicy import LearningPolicy
+
+
+class Actions(object):
+    """The 11 discrete GA3C-CADRL actions (reference policies/GA3C_CADRL/network.py:7-16): [speed factor, dheading]."""
+
+    def __init__(self):
+        s6, s12 = np.pi / 6, np.pi / 12
+        self.actions = np.array([[1, -s6], [1, -s12], [1, 0], [1, s12], [1, s6], [0.5, -s6], [0.5, 0], [0.5, s6],
+                                 [0, -s6], [0, 0], [0, s6]], dtype=np.float64)
+        self.num_actions = len(self.actions)
+
+
+class LearningPolicyGA3C(LearningPolicy):
+    """Discrete external action index -> [pref_speed * a0, a1] (reference policies/LearningPolicyGA3C.py:24-26).
+    The index travels in ext_actions[..., 0]."""
+    kernel_id = nat.POL_LEARNING_GA3C
+
+    def __init__(self):
+        LearningPolicy.__init__(self)
+        self.possible_actions = Actions()
+
+    def external_action_to_action(self, agent, external_action):
+        raw = self.possible_actions.actions[int(external_action)]
+        return np.array([agent.pref_speed * raw[0], raw[1]])

@@ -1,0 +1,45 @@
+"""Evaluation plumbing (reference: gym_collision_avoidance/experiments/src/env_utils.py:15-99)."""
+import numpy as np
+
+from gym_collision_avoidance_amd.envs import Config
+from gym_collision_avoidance_amd.envs.collision_avoidance_env import CollisionAvoidanceEnv
+from gym_collision_avoidance_amd.envs.wrappers import FlattenDictWrapper, MultiagentDictToMultiagentArrayWrapper
+
+
+def create_env(num_envs=1, device="cuda:0"):
+    """The env wrapped so observations are arrays (env_utils.py:15-42)."""
+    env = CollisionAvoidanceEnv(num_envs=num_envs, device=device)
+    if Config.TRAIN_SINGLE_AGENT:
+        return FlattenDictWrapper(env, dict_keys=Config.STATES_IN_OBS)
+    return MultiagentDictToMultiagentArrayWrapper(env, dict_keys=Config.STATES_IN_OBS,
+                                                  max_num_agents=Config.MAX_NUM_AGENTS_IN_ENVIRONMENT)
+
+
+def run_episode(env, max_steps=100000):
+    """Step a single env until game over and return (episode_stats, agents) with the reference's statistics schema
+    (env_utils.py:45-91).  For thousands of envs use CollisionAvoidanceEnv.set_fixture_suite + episode_stats(): the
+    same quantities are reduced to counters on the device."""
+    total_reward, step, terminated = 0, 0, False
+    while not terminated and step < max_steps:
+        obs, rew, terminated, truncated, info = env.step(None)
+        total_reward += rew
+        step += 1
+    agents = env.agents
+    time_to_goal = np.array([a.t for a in agents])
+    extra_time_to_goal = np.array([a.t - a.straight_line_time_to_reach_goal for a in agents])
+    collision = bool(np.any([a.in_collision for a in agents]))
+    all_at_goal = bool(np.all([a.is_at_goal for a in agents]))
+    any_stuck = bool(np.any([not a.in_collision and not a.is_at_goal for a in agents]))
+    outcome = "collision" if collision else "all_at_goal" if all_at_goal else "stuck"
+    stats = {"total_reward": total_reward, "steps": step, "num_agents": len(agents), "time_to_goal": time_to_goal,
+             "total_time_to_goal": np.sum(time_to_goal), "extra_time_to_goal": extra_time_to_goal,
+             "collision": collision, "all_at_goal": all_at_goal, "any_stuck": any_stuck, "outcome": outcome,
+             "policies": [a.policy.str for a in agents]}
+    frozen = [a.__deepcopy__({}) for a in agents]   # the views follow the device state, which reset() rewrites
+    env.reset()
+    return stats, frozen
+
+
+def store_stats(df, hyperparameters, episode_stats):
+    import pandas as pd
+    return pd.concat([df, pd.DataFrame([{**hyperparameters, **episode_stats}])], ignore_index=True)

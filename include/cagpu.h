@@ -76,6 +76,10 @@ typedef struct CaParams {
   int32_t max_obs;           /* K = MAX_NUM_OTHER_AGENTS_OBSERVED; obs row = 6 + 7*K floats */
   int32_t sort_mode, game_over_mode;
   int32_t rvo_max_neighbors; /* MAX_NUM_AGENTS_IN_ENVIRONMENT (RVOPolicy.py:15) */
+  int32_t obs_clip;          /* OtherAgentsStatesSensor.max_num_other_agents_observed (<= max_obs): only the
+                                obs_clip closest others are emitted, the remaining rows stay zero
+                                (OtherAgentsStatesSensor.py:39,112) */
+  int32_t reserved0;
   double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
   double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
   double reward_min, reward_max; /* np.clip bounds (collision_avoidance_env.py:589-599) */

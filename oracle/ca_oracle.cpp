@@ -98,7 +98,8 @@ void sense(const OrcParams& p, const OrcState& s, int e, int a, double* row) {
     if (x.key != y.key) return x.key < y.key;
     return x.p_orth < y.p_orth;
   });
-  if (static_cast<int>(c.size()) > K) c.resize(K);
+  const int clip = p.obs_clip < K ? p.obs_clip : K;  // :39 clip to the sensor's own limit; rows stay K (:112)
+  if (static_cast<int>(c.size()) > clip) c.resize(clip);
   if (p.sort_mode == ORC_SORT_CLOSEST_LAST) {
     std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) {
       if (-x.key != -y.key) return -x.key < -y.key;

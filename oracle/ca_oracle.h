@@ -40,7 +40,8 @@ enum { ORC_SORT_CLOSEST_FIRST = 0, ORC_SORT_CLOSEST_LAST = 1, ORC_SORT_TIME_TO_I
 enum { ORC_OVER_ALL_DONE = 0 /* EVALUATE_MODE */, ORC_OVER_AGENT0 = 1 /* TRAIN_SINGLE_AGENT */, ORC_OVER_LEARNING_DONE = 2 };
 
 typedef struct {
-  int32_t num_envs, num_agents, max_obs /* K */, sort_mode, game_over_mode, rvo_max_neighbors;
+  int32_t num_envs, num_agents, max_obs /* K: rows of the obs array */, sort_mode, game_over_mode, rvo_max_neighbors;
+  int32_t obs_clip /* sensor.max_num_other_agents_observed <= K */, reserved0;
   double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
   double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
   double reward_min, reward_max; /* np.clip bounds, env.py:589-599 */

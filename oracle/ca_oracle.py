@@ -29,7 +29,7 @@ _U8 = C.POINTER(C.c_uint8)
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_agents", "max_obs", "sort_mode", "game_over_mode",
-                                         "rvo_max_neighbors")] + \
+                                         "rvo_max_neighbors", "obs_clip", "reserved0")] + \
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
@@ -69,11 +69,13 @@ def lib():
 
 
 def default_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, sort_mode=SORT_CLOSEST_FIRST,
-                   game_over_mode=OVER_ALL_DONE, rvo_max_neighbors=None, near_goal=0.2, getting_close=0.2):
+                   game_over_mode=OVER_ALL_DONE, rvo_max_neighbors=None, near_goal=0.2, getting_close=0.2,
+                   obs_clip=None):
     """Constants of the reference Config (config.py:28-86) for an EvaluateConfig-style run (config.py:193-200)."""
     p = OrcParams()
     p.num_envs, p.num_agents = num_envs, num_agents
     p.max_obs = num_agents - 1 if max_obs is None else max_obs
+    p.obs_clip = p.max_obs if obs_clip is None else obs_clip
     p.sort_mode, p.game_over_mode = sort_mode, game_over_mode
     p.rvo_max_neighbors = num_agents if rvo_max_neighbors is None else rvo_max_neighbors
     p.dt, p.near_goal_threshold, p.max_time_ratio = dt, near_goal, max_time_ratio

@@ -1,0 +1,60 @@
+"""Config classes for the env-API tests, selected through GYM_CONFIG_PATH / GYM_CONFIG_CLASS exactly like a user
+would (they mirror oracle/golden_configs.py, which configured the REFERENCE when the golden vectors were recorded)."""
+import importlib.util
+import os
+
+_p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gym_collision_avoidance_amd", "envs",
+                  "config.py")
+_spec = importlib.util.spec_from_file_location("_amd_config", _p)
+_mod = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_mod)
+Config = _mod.Config
+
+
+class _Eval(Config):
+    N_MAX, K, SORT = 10, None, "closest_first"
+
+    def __init__(self):
+        self.MAX_NUM_AGENTS_IN_ENVIRONMENT = self.N_MAX
+        if self.K is not None:
+            self.MAX_NUM_OTHER_AGENTS_OBSERVED = self.K
+        Config.__init__(self)
+        self.EVALUATE_MODE, self.TRAIN_MODE = True, False
+        self.DT, self.MAX_TIME_RATIO = 0.1, 8.0
+        self.STORE_HISTORY = False
+        self.AGENT_SORTING_METHOD = self.SORT
+
+
+class Bench10(_Eval):
+    N_MAX = 10
+
+
+class Swap4(_Eval):
+    N_MAX = 4
+
+
+class Small3(_Eval):
+    N_MAX = 3
+
+
+class Clip6(_Eval):
+    N_MAX, K, SORT = 6, 3, "closest_last"
+
+
+class Pad5(_Eval):
+    N_MAX, K = 5, 7
+
+
+class Hist4(_Eval):
+    N_MAX = 4
+
+    def __init__(self):
+        _Eval.__init__(self)
+        self.STORE_HISTORY = True
+
+
+class Train5(Config):
+    def __init__(self):
+        self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 5
+        Config.__init__(self)
+        self.STORE_HISTORY = False

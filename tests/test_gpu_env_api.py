@@ -1,0 +1,161 @@
+"""The reference-shaped API (CollisionAvoidanceEnv / Agent / Policy / Dynamics / Sensor mirror) on the GPU, replayed
+against the vectors recorded from the unmodified reference (tests/golden/).  These read like the reference's own
+usage: build Agents, env.set_agents, env.reset, env.step(actions dict)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests import envtools
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"rvo10": "Bench10", "rvo4_swap": "Swap4", "rvo3": "Small3", "noncoop10": "Bench10", "clip6_rvo": "Clip6",
+       "mixed5": "Pad5", "train5": "Train5"}
+POL = {0: "RVO", 1: "noncoop", 2: "static", 3: "external", 4: "learning"}
+DYN = {0: "unicycle", 1: "unicycle_max_turn_rate", 2: "external"}
+TOL = 1e-4      # free-running episode (see test_gpu_parity.test_golden_free_running for why not 1e-5)
+TOLH = 1e-3
+
+
+def _agents(tc, ep):
+    from gym_collision_avoidance_amd.envs.agent import Agent
+    from gym_collision_avoidance_amd.envs.sensors import OtherAgentsStatesSensor
+    cases, head = ep.case()
+    return [Agent(c[0], c[1], c[2], c[3], c[5], c[4], head[i], tc.policy_dict[POL[int(ep.policy[i])]],
+                  tc.dynamics_dict[DYN[int(ep.dynamics[i])]], [OtherAgentsStatesSensor], i)
+            for i, c in enumerate(cases)]
+
+
+def _obs_array(obs, n, states):
+    return np.array([np.concatenate([np.asarray(obs[i][s], dtype=np.float64).reshape(-1) for s in states])
+                     for i in range(n)])
+
+
+@pytest.mark.parametrize("name", gu.SCENARIOS)
+def test_env_api_replays_reference_episode(name):
+    Config, tc, Env = envtools.fresh(CFG[name])
+    meta, eps = gu.load(name)
+    assert Config.MAX_NUM_OTHER_AGENTS_OBSERVED == meta["K"] and Config.DT == meta["dt"]
+    for c, ep in eps.items():
+        env = Env()
+        agents = _agents(tc, ep)
+        env.set_agents(agents)
+        obs, info = env.reset()
+        assert info == {}
+        assert set(obs.keys()) == set(range(Config.MAX_NUM_AGENTS_IN_ENVIRONMENT))
+        np.testing.assert_allclose(_obs_array(obs, ep.N, meta["states"]), ep.obs[0], rtol=0, atol=1e-5)
+        ext_idx = [i for i, a in enumerate(agents) if a.policy.is_external]
+        for t in range(ep.T):
+            actions = {i: ep.ext[t][i] for i in ext_idx}
+            obs, rew, over, trunc, info = env.step(actions)
+            assert trunc is False
+            assert over == bool(ep.game_over[t]), "game_over @%d" % t
+            assert [info["which_agents_done"][a.id] for a in agents] == list(ep.done[t].astype(bool)), "done @%d" % t
+            np.testing.assert_allclose(np.atleast_1d(rew), ep.rewards[t], rtol=0, atol=1e-5, err_msg="rew @%d" % t)
+            got = _obs_array(obs, ep.N, meta["states"])
+            assert np.array_equal(got[:, 1], ep.obs[t + 1][:, 1])
+            np.testing.assert_allclose(got, ep.obs[t + 1], rtol=0, atol=TOLH, err_msg="obs @%d" % t)
+            # the Agent views follow the device state
+            for i, a in enumerate(agents):
+                np.testing.assert_allclose(a.pos_global_frame, [ep.col(t + 1, "pos_x")[i], ep.col(t + 1, "pos_y")[i]],
+                                           rtol=0, atol=TOL)
+                f = int(ep.flags[t + 1][i])
+                assert (a.is_at_goal, a.in_collision, a.ran_out_of_time, a.is_done) == \
+                       (bool(f & 1), bool(f & 4), bool(f & 16), bool(f & 32))
+                assert abs(a.t - ep.col(t + 1, "t")[i]) < 1e-9
+        assert env.episode_step_number == ep.T
+
+
+def test_example_script_config1():
+    """BASELINE.json configs[0]: 4-agent swap, RVO + unicycle, single env (reference test_example_script)."""
+    envtools.fresh("Swap4")
+    import importlib
+    ex = importlib.import_module("gym_collision_avoidance_amd.experiments.example")
+    ok, at_goal = ex.main(verbose=False)
+    assert ok and all(at_goal)
+
+
+def test_user_python_policy_uses_host_fallback():
+    """A user InternalPolicy subclass is queried through find_next_action(obs, agents, i), like in the reference."""
+    Config, tc, Env = envtools.fresh("Swap4")
+    from gym_collision_avoidance_amd.envs.agent import Agent
+    from gym_collision_avoidance_amd.envs.policies import InternalPolicy, NonCooperativePolicy
+    from gym_collision_avoidance_amd.envs.dynamics import UnicycleDynamics
+    from gym_collision_avoidance_amd.envs.sensors import OtherAgentsStatesSensor
+
+    class MyPolicy(InternalPolicy):
+        calls = 0
+
+        def __init__(self):
+            InternalPolicy.__init__(self, str="mine")
+
+        def find_next_action(self, obs, agents, i):
+            MyPolicy.calls += 1
+            assert "other_agents_states" in obs
+            return np.array([agents[i].pref_speed, -agents[i].heading_ego_frame])   # == NonCooperativePolicy
+
+    def build(pol):
+        return [Agent(-3, 0.3, 3, -0.2, 0.3, 1.0, None, pol, UnicycleDynamics, [OtherAgentsStatesSensor], 0),
+                Agent(3, 4.0, -3, 4.1, 0.3, 0.8, None, NonCooperativePolicy, UnicycleDynamics,
+                      [OtherAgentsStatesSensor], 1)]
+
+    traj = []
+    for pol in (MyPolicy, NonCooperativePolicy):
+        env = Env()
+        env.set_agents(build(pol))
+        env.reset()
+        for _ in range(30):
+            env.step({})
+        traj.append(np.array([a.pos_global_frame for a in env.agents]))
+    assert MyPolicy.calls == 30
+    np.testing.assert_allclose(traj[0], traj[1], rtol=0, atol=1e-6)
+
+
+def test_batched_fixture_suite_and_stats():
+    Config, tc, Env = envtools.fresh("Bench10")
+    E = 200
+    env = Env(num_envs=E)
+    env.set_fixture_suite(10, "RVO")
+    obs, _ = env.reset()
+    assert tuple(obs.shape) == (E, 10, 6 + 7 * 9) and obs.is_cuda
+    for _ in range(400):
+        obs, rew, over, trunc, info = env.step(None)
+    assert tuple(rew.shape) == (E, 10) and tuple(over.shape) == (E,)
+    assert info["which_agents_done"].shape == (E, 10)
+    st = env.episode_stats()
+    assert st["episodes"] >= E * 0.8 and st["episodes"] == st["collision_episodes"] + st["all_at_goal_episodes"] + \
+        st["stuck_episodes"]
+    assert st["all_at_goal_episodes"] > 0.7 * st["episodes"]
+    # the array wrapper is a pass-through in batched mode
+    from gym_collision_avoidance_amd.envs.wrappers import MultiagentDictToMultiagentArrayWrapper
+    w = MultiagentDictToMultiagentArrayWrapper(env, Config.STATES_IN_OBS, Config.MAX_NUM_AGENTS_IN_ENVIRONMENT)
+    assert w.observation(obs) is obs and w.obs_shape == (10, 69)
+
+
+def test_run_episode_statistics_schema():
+    Config, tc, Env = envtools.fresh("Swap4")
+    from gym_collision_avoidance_amd.experiments.env_utils import create_env, run_episode
+    env = create_env()
+    env.set_agents(tc.full_test_suite(4, 0, policies="RVO"))
+    env.reset()
+    stats, agents = run_episode(env)
+    assert stats["outcome"] == "all_at_goal" and stats["steps"] == 60 and stats["num_agents"] == 4
+    assert stats["total_reward"].shape == (4,) and np.allclose(stats["total_reward"].max(), 1.0, atol=0.3)
+    assert len(stats["time_to_goal"]) == 4 and (stats["extra_time_to_goal"] >= -1e-9).all()
+    assert all(a.is_at_goal for a in agents)
+
+
+def test_history_and_set_state():
+    Config, tc, Env = envtools.fresh("Hist4")
+    env = Env()
+    env.set_agents(tc.full_test_suite(4, 3, policies="noncoop"))
+    env.reset()
+    for _ in range(12):
+        env.step(None)
+    h = env.agents[0].global_state_history
+    assert h.shape == (12, 11) and np.allclose(h[:, 0], np.arange(12) * 0.1)
+    a = env.agents[1]
+    a.set_state(1.25, -0.5, vx=0.0, vy=0.3, heading=1.0)
+    assert np.allclose(a.pos_global_frame, [1.25, -0.5]) and abs(a.heading_global_frame - 1.0) < 1e-12

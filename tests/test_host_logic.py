@@ -1,0 +1,189 @@
+"""CPU-only tests: the C-ABI library exports what include/cagpu.h declares, the host-side mirror of the reference
+interface (Config / Agent / registries / wrappers / sharding), and the multi-process (gloo) path.  No kernels run."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import envtools
+from tests import golden_util as gu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "cagpu.h")).read()
+    declared = set(re.findall(r"\b(cagpu_[a-z_]+)\s*\(", hdr))
+    assert {"cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_rollout", "cagpu_orca",
+            "cagpu_observe"} <= declared
+    so = os.path.join(REPO, "gym_collision_avoidance_amd", "libcagpu.so")
+    if not os.path.exists(so):
+        from gym_collision_avoidance_amd import build_native
+        build_native.build()
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.cagpu_version.restype = ctypes.c_int
+    assert lib.cagpu_version() == 1   # host-only call, no GPU needed
+
+
+def test_ctypes_structs_match_header_layout():
+    from gym_collision_avoidance_amd import _native as nat
+    assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 15 * 8
+    assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
+    assert ctypes.sizeof(nat.CaAutoReset) == 32
+    assert nat.CaParams.dt.offset == 32
+
+
+def test_bad_arguments_are_loud_errors_not_crashes():
+    from gym_collision_avoidance_amd import _native as nat, core
+    lib = nat.lib()
+    assert lib.cagpu_step(None, None, None, None, None, None) == nat.CA_EINVAL
+    assert b"NULL" in lib.cagpu_last_error()
+    p = core.make_params(4, 70)
+    s, o = nat.CaState(), nat.CaOut()
+    assert lib.cagpu_observe(ctypes.byref(p), ctypes.byref(s), ctypes.byref(o), None) == nat.CA_EUNSUPPORTED
+    with pytest.raises(nat.CagpuError):
+        nat.check(-2)
+
+
+def test_no_cpu_fallback_in_product_path():
+    import torch
+    from gym_collision_avoidance_amd import _native as nat, core
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nat.CagpuError):
+        core.BatchedSim(core.make_params(2, 3))
+    for root, _, files in os.walk(os.path.join(REPO, "gym_collision_avoidance_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_config_singleton_and_env_var_selection():
+    Config, tc, Env = envtools.fresh("Clip6")
+    assert Config.MAX_NUM_AGENTS_IN_ENVIRONMENT == 6 and Config.MAX_NUM_OTHER_AGENTS_OBSERVED == 3
+    assert Config.AGENT_SORTING_METHOD == "closest_last" and Config.DT == 0.1 and Config.EVALUATE_MODE
+    assert Config.STATE_INFO_DICT["other_agents_states"]["size"] == (3, 7)
+    envtools.default()
+    from gym_collision_avoidance_amd.envs import Config as C0
+    assert C0.DT == 0.2 and C0.MAX_NUM_AGENTS_IN_ENVIRONMENT == 4 and C0.MAX_TIME_RATIO == 2.0
+    assert C0.STATES_IN_OBS[0] == "is_learning" and C0.RVO_TIME_HORIZON == 5.0
+
+
+def test_agent_initial_condition_matches_reference_reset():
+    """Agent.reset arithmetic (agent.py:59-138) against the t=0 record of the reference"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    meta, eps = gu.load("rvo10")
+    ep = eps[0]
+    agents = tc.full_test_suite(10, 0, policies="RVO")
+    for i, a in enumerate(agents):
+        assert np.allclose(a.pos_global_frame, [ep.col(0, "pos_x")[i], ep.col(0, "pos_y")[i]], atol=0)
+        assert abs(a.heading_global_frame - ep.col(0, "heading")[i]) < 1e-15
+        assert abs(a.time_remaining_to_reach_goal - ep.col(0, "time_remaining")[i]) < 1e-12
+        assert abs(a.straight_line_time_to_reach_goal - ep.col(0, "slt")[i]) < 1e-12
+        assert abs(a.dist_to_goal - ep.obs[0][i, 2]) < 1e-12 and abs(a.heading_ego_frame - ep.obs[0][i, 3]) < 1e-12
+        assert not a.is_done and a.t == 0.0 and a.policy.str == "RVO" and not a.policy.is_external
+
+
+def test_registries_and_plugin_flags():
+    Config, tc, Env = envtools.fresh("Swap4")
+    from gym_collision_avoidance_amd import _native as nat
+    assert set(tc.policy_dict) >= {"RVO", "noncoop", "static", "external", "learning", "learning_ga3c"}
+    ids = {k: tc.policy_dict[k].kernel_id for k in ("RVO", "noncoop", "static", "external", "learning", "learning_ga3c")}
+    assert ids == {"RVO": nat.POL_RVO, "noncoop": nat.POL_NONCOOP, "static": nat.POL_STATIC,
+                   "external": nat.POL_EXTERNAL, "learning": nat.POL_LEARNING, "learning_ga3c": nat.POL_LEARNING_GA3C}
+    lp = tc.policy_dict["learning"]()
+    assert lp.is_external and lp.is_still_learning and lp.str == "learning"
+    ag = tc.get_testcase_two_agents()
+    act = lp.external_action_to_action(ag[0], np.array([0.5, 1.0]))
+    assert np.allclose(act, [0.5, math.pi / 3])
+    g = tc.policy_dict["learning_ga3c"]()
+    assert np.allclose(g.external_action_to_action(ag[0], 7), [0.5, math.pi / 6])
+    assert tc.fixture_table(10).shape == (500, 10, 6) and len(tc.preset_testCases(4, full_test_suite=True)) == 500
+    s = tc.sensor_dict["other_agents_states"]()
+    s.set_args({"max_num_other_agents_observed": 2, "agent_sorting_method": "closest_last"})
+    assert s.max_num_other_agents_observed == 2 and s.name == "other_agents_states"
+    with pytest.raises(NotImplementedError):
+        tc.get_testcase_random()
+
+
+def test_env_constructs_without_gpu_and_checks_arguments():
+    Config, tc, Env = envtools.fresh("Swap4")
+    env = Env()
+    assert env.num_agents == 4 and env.dt_nominal == 0.1 and env.episode_step_number is None
+    assert env.action_space.low.tolist() == [0.0, -math.pi / 3] and env.max_possible_reward == 1.0
+    assert set(env.observation[0]) == set(Config.STATES_IN_OBS)
+    assert env.observation_space.spaces[3]["other_agents_states"].shape == (3, 7)
+    with pytest.raises(RuntimeError):
+        env.step({})
+    with pytest.raises(AssertionError):
+        env.set_testcase("no_such_fn", {})
+
+
+def test_array_wrapper_layout():
+    Config, tc, Env = envtools.fresh("Bench10")
+    from gym_collision_avoidance_amd.envs.wrappers import (MultiagentDictToMultiagentArrayWrapper,
+                                                           MultiagentFlattenDictWrapper)
+    env = Env()
+    w = MultiagentDictToMultiagentArrayWrapper(env, Config.STATES_IN_OBS, 10)
+    assert w.obs_shape == (10, 69)
+    assert w.observation_indices[3]["other_agents_states"] == [6, 69] and w.observation_indices[0]["radius"] == [5, 6]
+    arr = w.observation(env.observation)
+    assert arr.shape == (10, 69) and not arr.any()
+    f = MultiagentFlattenDictWrapper(env, Config.STATES_IN_OBS, 10)
+    assert f.obs_shape == (690,) and f.observation_indices[1]["BOUNDS"] == [69, 138]
+
+
+def test_shard_env_ids():
+    from gym_collision_avoidance_amd.sharding import shard_env_ids
+    assert shard_env_ids(0, 1, 4096) == (0, 4096)
+    assert shard_env_ids(3, 8, 4096) == (3 * 4096, 8 * 4096)
+    with pytest.raises(ValueError):
+        shard_env_ids(8, 8, 1)
+    # shards replay disjoint case streams, exactly as one big batch would
+    seen = set()
+    for r in range(4):
+        off, stride = shard_env_ids(r, 4, 5)
+        for e in range(5):
+            for k in range(3):
+                seen.add((off + e + k * stride))
+    assert seen == set(range(60))
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from gym_collision_avoidance_amd.sharding import shard_env_ids, reduce_episode_stats, gather_episode_stats
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+off, stride = shard_env_ids(rank, world, 16)
+stats = torch.arange(8, dtype=torch.float64) * (rank + 1)
+tot = reduce_episode_stats(stats)
+allg = gather_episode_stats(stats)
+assert torch.equal(tot, torch.arange(8, dtype=torch.float64) * 3), tot
+assert allg.shape == (2, 8) and torch.equal(allg[1], torch.arange(8, dtype=torch.float64) * 2)
+assert torch.equal(stats, torch.arange(8, dtype=torch.float64) * (rank + 1))   # input untouched
+assert (off, stride) == (16 * rank, 32)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_process_stats_reduction_gloo(tmp_path):
+    """the N>1 path on CPU: one process per shard, gloo backend, world_size 2"""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
