@@ -25,6 +25,17 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic_bytes(envs, agents):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, profiles/), if they were
+    taken at this geometry; bench.py itself does not run the profiler."""
+    f = os.path.join(REPO, "profiles", "r01_traffic.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        if d.get("envs") == envs and d.get("agents") == agents:
+            return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0
+    return None
+
+
 def algorithmic_bytes_per_agent_step(K):
     """read 44 B + write state 28 B + outputs (32 + 28 K) B = 104 + 28 K (356 B at K=9)."""
     return 104 + 28 * K
@@ -137,8 +148,11 @@ def main():
                                    "fixture 10_agents_500_cases, auto-reset" % (E, N, K),
                        "envs_per_gpu": E, "agents": N, "launch_mode": a.mode, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ca_kernel<64>", "avg_launch_us": kern_s * 1e6,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic_bytes(E, N) if a.mode == "step" else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_rocprof_summary.md)",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": "ca_kernel<128>", "avg_launch_us": kern_s * 1e6,
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
         }
