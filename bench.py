@@ -156,6 +156,19 @@ def main():
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
         }
+        if world == 1 and a.mode == "step":
+            # extra: the same K steps fused into ONE cagpu_rollout launch (env_utils.run_episode's loop on the device)
+            torch.cuda.synchronize(dev)
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
+            sim.rollout(a.steps)
+            r1.record()
+            torch.cuda.synchronize(dev)
+            rms = r0.elapsed_time(r1)
+            out["rollout"] = {"value": E * N * a.steps / (rms * 1e-3), "unit": "agent-steps/s",
+                              "ms_per_step": rms / a.steps, "launches": 1,
+                              "note": "same workload, %d steps in one launch (state stays in registers/LDS between "
+                                      "steps; observations, rewards and done flags are still written every step)" % a.steps}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))

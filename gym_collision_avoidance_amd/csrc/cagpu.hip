@@ -78,8 +78,12 @@ __device__ __forceinline__ F2 over(F2 a, float s) { const float inv = divf(1.0f,
 __device__ __forceinline__ F2 unitf(F2 a) { return over(a, sqrtf_rn(dotf(a, a))); }
 
 __device__ __forceinline__ double wrap_pi(double a) {  // util.py:141-146 ([-pi, pi))
-  for (int it = 0; it < 4096 && a >= kPi; ++it) a -= kTwoPi;
-  for (int it = 0; it < 4096 && a < -kPi; ++it) a += kTwoPi;
+  if (a >= kPi) a -= kTwoPi;   // first iteration of the reference's while loops, branch-free
+  if (a < -kPi) a += kTwoPi;
+  if (!(a < kPi) || a < -kPi) {  // more than one turn out of range: the general loops (bounded)
+    for (int it = 0; it < 4096 && a >= kPi; ++it) a -= kTwoPi;
+    for (int it = 0; it < 4096 && a < -kPi; ++it) a += kTwoPi;
+  }
   return a;
 }
 
@@ -328,7 +332,7 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT>
+template <int NT, bool STAGE>
 __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
@@ -471,8 +475,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           int rank = 0, cnt = 0;
           for (int q = 0; q < N; ++q) {
             const float dq = dmat[q * ROW + ag];
-            rank += (dq < dj) || (dq == dj && q < j);
-            cnt += (dq < INFINITY);
+            rank += (dq < dj) ? 1 : ((dq == dj) ? ((q < j) ? 1 : 0) : 0);
+            cnt += (dq < INFINITY) ? 1 : 0;
           }
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (j == aa) {
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           sh_r2[lane] = r.t - r.slt;
         }
         if (do_sense) {
-          float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
+          float* row = STAGE ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
           row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
           row[2] = static_cast<float>(eg.dist);
           row[3] = static_cast<float>(eg.heading_ego);
@@ -681,11 +685,11 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         int rank = 0, cnt = 0;
         for (int q = 0; q < N; ++q) {
           const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-          rank += (kq < kj) || (kq == kj && (oq < oj || (oq == oj && q < j)));
-          cnt += (kq < INFINITY);
+          rank += (kq < kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0);
+          cnt += (kq < INFINITY) ? 1 : 0;
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
-        float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+        float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
         if (j == aa) row[1] = static_cast<float>(keep);  // num_other_agents_observed
         for (int sl = j; sl < K; sl += N)                // zero the unfilled rows (sensor :112)
           if (sl >= keep) {
@@ -726,9 +730,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             const int rq = rmat[q * ROW + ag];
             if (rq >= N) continue;
             const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-            r2 += (kq > kj) || (kq == kj && (oq < oj || (oq == oj && rq < rank)));
+            r2 += (kq > kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((rq < rank) ? 1 : 0) : 0)) : 0);
           }
-          float* row = k.stage_obs ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+          float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
           const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       TICK(10);
       if (!again) {
         // ---- the tile's observation block leaves LDS as one contiguous, coalesced copy
-        if (k.stage_obs && !AB(128)) {
+        if (STAGE && !AB(128)) {
           const long total = tile_cnt * W;
           float* dst = k.o.obs + tile_base * W;
           if (k.mode == MODE_RESET && k.reset_mask) {
@@ -848,6 +852,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
     if (a == 0) { ka->s.episode_step[e] = ep_step; ka->s.reset_count[e] = reset_cnt; }
   }
 }
+
+#include "cagpu_g16.inc"
 
 // ---------------------------------------------------------------- stand-alone ORCA (rvo2 doStep replacement)
 struct OrcaArgs {
@@ -921,28 +927,60 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT>
-int launch_main(const KArgs& k, hipStream_t st) {
-  const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
-  KArgs kk = k;
-  const size_t un_orca = lds_orca_bytes(N);
-  size_t un_sense = lds_sense_bytes(N, W, 1);
-  kk.stage_obs = 1;
-  size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
-  if (total > 64 * 1024) {  // keep >= 2 workgroups per CU when possible: give up the staging area first
-    un_sense = lds_sense_bytes(N, W, 0);
-    kk.stage_obs = 0;
-    total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
-  }
-  if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
+template <int NT, bool STAGE>
+int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int tile_envs = ROW / N;
+  const int tile_envs = ROW / k.p.num_agents;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL(ca_kernel<NT>, dim3(grid), dim3(NT), total, st, kk);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE>), dim3(grid), dim3(NT), total, st, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
+}
+
+template <int NT>
+int launch_main(const KArgs& k, hipStream_t st) {
+  const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
+  const size_t un_orca = lds_orca_bytes(N);
+  size_t un_sense = lds_sense_bytes(N, W, 1);
+  bool stage = true;
+  size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
+  if (total > 64 * 1024) {  // keep >= 2 workgroups per CU when possible: give up the staging area first
+    un_sense = lds_sense_bytes(N, W, 0);
+    stage = false;
+    total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
+  }
+  if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
+  return stage ? launch_main2<NT, true>(k, total, st) : launch_main2<NT, false>(k, total, st);
+}
+
+// ---- launcher of the 16-lane-group kernel (num_agents <= 16)
+template <int NC>
+int launch_g16(const KArgs& k, hipStream_t st) {
+  const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
+  int epw = 20 / N;  // ~20 agents (5 waves) per workgroup
+  if (epw < 1) epw = 1;
+  if (const char* e = std::getenv("CAGPU_EPW")) epw = std::atoi(e);  // experiments
+  if (epw * N > TMAX16) epw = TMAX16 / N;
+  constexpr int TM = NC ? ((20 / NC) > 0 ? (20 / NC) * NC : NC) : TMAX16;
+  if (NC) epw = TM / NC;  // the specialised instantiation has its tile size baked in
+  KArgs kk = k;
+  kk.stage_obs = epw;
+  const int T = epw * N;
+  const int nt = ((T + 3) / 4) * 64;
+  const size_t total = align16(sizeof(G16Lds<TM>)) + align16(static_cast<size_t>(TM) * W * 4);
+  if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: max_obs too large for the LDS staging area%s");
+  if (total > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel16<NC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
+    if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const unsigned grid = static_cast<unsigned>((k.p.num_envs + epw - 1) / epw);
+  hipLaunchKernelGGL(ca_kernel16<NC>, dim3(grid), dim3(nt), total, st, kk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
@@ -955,6 +993,10 @@ int launch_main(const KArgs& k, hipStream_t st) {
 int launch_any(const KArgs& k, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = k.p.num_agents;
+  if (N <= G16 && std::getenv("CAGPU_G16")) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
+    if (N == 10) return launch_g16<10>(k, st);
+    return launch_g16<0>(k, st);
+  }
   const int items = (ROW / N) * N * N;
   (void)items;
   int nt = 128;
