@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--mode", choices=["step", "rollout"], default="step",
                     help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (lets a 1-GPU box exercise the N>1 code path with gloo)")
     a = ap.parse_args()
 
     import torch
@@ -85,8 +88,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if a.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 

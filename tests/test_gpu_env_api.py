@@ -161,3 +161,23 @@ def test_history_and_set_state():
     a = env.agents[1]
     a.set_state(1.25, -0.5, vx=0.0, vy=0.3, heading=1.0)
     assert np.allclose(a.pos_global_frame, [1.25, -0.5]) and abs(a.heading_global_frame - 1.0) < 1e-12
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """the N>1 path of bench.py end to end (sharded case streams + stats all-reduce), two ranks sharing cuda:0 over
+    gloo -- the driver runs the real thing on 8 GPUs over RCCL"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    env.pop("GYM_CONFIG_CLASS", None); env.pop("GYM_CONFIG_PATH", None)
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "20", "--envs",
+           "256", "--backend", "gloo", "--share-device", "--no-cpu-baseline"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-800:] for o in outs]
+    line = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["episode_stats"]["episodes"] > 2 * 256 * 0.8      # both shards' episodes were summed
+    assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
