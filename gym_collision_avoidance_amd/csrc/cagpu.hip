@@ -332,11 +332,12 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT, bool STAGE>
+template <int NT, bool STAGE, int NC, bool MULTI>
 __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
-  const int N = p.num_agents, K = p.max_obs, W = 6 + 7 * K;
+  const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
+  const int K = p.max_obs, W = 6 + 7 * K;
   const float inv_n = 1.0f / static_cast<float>(N);
   const int tile_envs = ROW / N;
   const int tile_n = tile_envs * N;
@@ -426,8 +427,23 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   __syncthreads();
   unsigned long long tprev_ = clock64();
 #endif
-  const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
-  for (int step = 0; step < n_steps; ++step) {
+  // The phases are straight-line code in the single-step kernel (lambdas inlined at their call sites): with the
+  // n-step loop and the two-pass sensing loop around them the register allocator keeps ~100 more VGPRs alive around
+  // the back edges (profiles/r01_kernel_geometry.md).  MULTI = true keeps the step loop for cagpu_rollout.
+  auto one_step = [&]() {
+    // In the n-step kernel, hide the loop invariance of everything derived from the thread id (one laundered copy
+    // per iteration): otherwise LICM hoists dozens of per-thread addresses / predicates out of the step loop and
+    // the allocator has to keep them alive across it.
+    int tid_l = threadIdx.x;
+    if (MULTI) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l;
+    const bool wave0 = tid < ROW;
+    const int lane = tid & (ROW - 1);
+    const int le = lane / N, a = lane - le * N;
+    const long e = env0 + le;
+    const bool active = wave0 && (lane < tile_n) && (e < p.num_envs);
+    const int ebase = active ? le * N : 0;
+    const long i = e * N + a;
     TICK(0);
     if (k.mode == MODE_STEP) {
       // ================= A1: who queries ORCA, float bodies (RVOPolicy.py:57-74)
@@ -505,6 +521,11 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             F2 v;
             int fail = n;
             if (AB(2)) v = pref; else fail = lp2<ROW>(Lmat + lane, n, ms, pref, false, v);
+            TICK(12);
+#ifdef CAGPU_ABLATE
+            if (fail < n) atomicAdd(&g_prof[14], 1ull);
+            atomicAdd(&g_prof[15], 1ull);
+#endif
             if (fail < n) lp3<ROW>(Lmat + lane, Pmat + lane, n, fail, ms, v);
             TICK(3);
             // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
@@ -589,7 +610,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
     }
 
     // ================= sensing passes: once, and a second time for envs that auto-reset in this step
-    for (int pass = 0; pass < 2; ++pass) {
+    auto sense_pass = [&](const int pass) -> int {
       // ---- A: publish the post-move tile + ego frames (agent.py:329-349, Dynamics.py:24-41)
       Ego eg;
       eg.dist = 0.0; eg.prx = eg.pry = eg.orx = eg.ory = eg.heading_ego = 0.0;
@@ -818,11 +839,19 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             for (long q = tid; q < total; q += NT) dst[q] = sh_obs[q];
           }
         }
-        break;
+        return 0;
       }
-    }
+      return 1;  // some env of the tile auto-reset: run the sensing pass once more for it
+    };
+    if (sense_pass(0)) sense_pass(1);
     __syncthreads();  // the union is free again before the next step's ORCA view
     TICK(11);
+  };
+  if (MULTI) {
+    const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
+    for (int step = 0; step < n_steps; ++step) one_step();
+  } else {
+    one_step();
   }
 
 #ifdef CAGPU_ABLATE
@@ -927,19 +956,31 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT, bool STAGE>
-int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
+template <int NT, bool STAGE, int NC, bool MULTI>
+int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int tile_envs = ROW / k.p.num_agents;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL((ca_kernel<NT, STAGE>), dim3(grid), dim3(NT), total, st, k);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
+}
+
+template <int NT, bool STAGE, int NC>
+int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
+  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_main4<NT, STAGE, NC, true>(k, total, st);
+  return launch_main4<NT, STAGE, NC, false>(k, total, st);
+}
+
+template <int NT, bool STAGE>
+int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
+  if (STAGE && k.p.num_agents == 10 && !std::getenv("CAGPU_NO_NC")) return launch_main3<NT, STAGE, 10>(k, total, st);
+  return launch_main3<NT, STAGE, 0>(k, total, st);
 }
 
 template <int NT>
@@ -959,7 +1000,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
 }
 
 // ---- launcher of the 16-lane-group kernel (num_agents <= 16)
-template <int NC>
+template <int NC, bool MULTI>
 int launch_g16(const KArgs& k, hipStream_t st) {
   const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
   int epw = 20 / N;  // ~20 agents (5 waves) per workgroup
@@ -975,34 +1016,37 @@ int launch_g16(const KArgs& k, hipStream_t st) {
   const size_t total = align16(sizeof(G16Lds<TM>)) + align16(static_cast<size_t>(TM) * W * 4);
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: max_obs too large for the LDS staging area%s");
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel16<NC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel16<NC, MULTI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + epw - 1) / epw);
-  hipLaunchKernelGGL(ca_kernel16<NC>, dim3(grid), dim3(nt), total, st, kk);
+  hipLaunchKernelGGL((ca_kernel16<NC, MULTI>), dim3(grid), dim3(nt), total, st, kk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }
 
-// Workgroup size.  Measured on MI355X at 4096 envs x 10 agents (profiles/r01_kernel_geometry.md): 128 threads
-// (wave 0 = agent lanes, wave 1 helps with the pair phases) gives 40.7 us/step in a fused rollout, 256 -> 57,
-// 512 -> 72: the kernel needs ~225 VGPRs, so only 8 waves fit a CU and larger workgroups stop being co-resident
-// (683 workgroups then run in ~3 rounds).  CAGPU_NT overrides for experiments.
+// Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md).
+//   single step (cagpu_step / reset / observe): the straight-line kernel needs ~90 VGPRs, so five 4-wave workgroups
+//     fit a CU and all 683 workgroups are co-resident: 256 threads -> 48 us, 128 -> 55, 384/512 -> 63.
+//   n-step rollout: the in-kernel step loop costs ~235 VGPRs (2 waves/SIMD): 128 threads -> 36.7 us/step, 256 -> 54.
+// CAGPU_NT overrides for experiments.
 int launch_any(const KArgs& k, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = k.p.num_agents;
   if (N <= G16 && std::getenv("CAGPU_G16")) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
-    if (N == 10) return launch_g16<10>(k, st);
-    return launch_g16<0>(k, st);
+    const bool multi = k.mode == MODE_STEP && k.n_steps > 1;
+    if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
+    return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);
   }
   const int items = (ROW / N) * N * N;
   (void)items;
-  int nt = 128;
+  int nt = (k.mode == MODE_STEP && k.n_steps > 1) ? 128 : 256;
   if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
   if (nt <= 128) return launch_main<128>(k, st);
   if (nt <= 256) return launch_main<256>(k, st);
+  if (nt <= 384) return launch_main<384>(k, st);
   return launch_main<512>(k, st);
 }
 

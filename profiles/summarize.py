@@ -33,15 +33,16 @@ def counters(d):
     meta = {}
     for r in csv.DictReader(open(f[0])):
         if "ca_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",
                                       "Scratch_Size")}
     print("## rocprofv3 --pmc (%s), ca_kernel dispatches only\n" % d)
     print("dispatch geometry:", meta, "\n")
-    print("| counter | dispatches | mean per dispatch | min | max |")
-    print("|---|---|---|---|---|")
-    for k, v in agg.items():
-        print("| %s | %d | %.1f | %.1f | %.1f |" % (k, len(v), sum(v) / len(v), min(v), max(v)))
+    print("| kernel | counter | dispatches | mean per dispatch | min | max |")
+    print("|---|---|---|---|---|---|")
+    for (kn, c), v in sorted(agg.items()):
+        print("| `%s` | %s | %d | %.1f | %.1f | %.1f |" % (kn, c, len(v), sum(v) / len(v), min(v), max(v)))
     print()
 
 

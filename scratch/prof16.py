@@ -8,9 +8,14 @@ sim = core.BatchedSim(core.make_params(E, N))
 sim.set_plugins(nat.POL_RVO); sim.set_fixture_table(table); sim.reset_from_table()
 L = nat.lib()
 buf = (C.c_ulonglong * 16)()
-sim.rollout(1500); L.cagpu_debug_prof(buf, 1)
+for _ in range(1500): sim.step()
+L.cagpu_debug_prof(buf, 1)
 steps = 500
-sim.rollout(steps); L.cagpu_debug_prof(buf, 1)
+import time
+torch.cuda.synchronize(); t0=time.perf_counter()
+for _ in range(steps): sim.step()
+torch.cuda.synchronize(); print('wall us/step', (time.perf_counter()-t0)/steps*1e6)
+L.cagpu_debug_prof(buf, 1)
 names = ["0 loop top", "1 S1 bodies+pref + barrier", "2 S2 dist/rank/half-plane (wave 0 of WG)", "3 S3 group LP + barrier", "4 S4 post/move (atan2,sincos)",
          "5 ego frames + barrier", "6 S5 pair gaps/keys/ranks/rows + barrier", "7 S6 reward + barrier", "8 S7 game over/reset + barriers", "9 copy-out + barrier"]
 epw = int(os.environ.get("CAGPU_EPW", "2"))
