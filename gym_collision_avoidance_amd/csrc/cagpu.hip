@@ -278,6 +278,47 @@ __device__ __forceinline__ Ego ego_frame(double px, double py, double gx, double
   return e;
 }
 
+// time to impact of `host` with `other` (util.py:23-83 compute_time_to_impact + :101-127 tangent_vecs_from_external_pt),
+// float64 in the numpy operation order; only used by the time_to_impact sorting mode of the sensor
+__device__ double time_to_impact(double hx, double hy, double ox, double oy, double hvx, double hvy, double ovx,
+                                 double ovy, double r) {
+  const double v0 = hvx - ovx, v1 = hvy - ovy;
+  const double xp = hx, yp = hy, a = ox, b = oy;
+  const double sq = (xp - a) * (xp - a) + (yp - b) * (yp - b) - r * r;
+  if (sq < 0) return 0.0;
+  const double st = sqrt(sq);
+  const double xnum1 = r * r * (xp - a), xnum2 = r * (yp - b) * st;
+  const double ynum1 = r * r * (yp - b), ynum2 = r * (xp - a) * st;
+  const double den = (xp - a) * (xp - a) + (yp - b) * (yp - b);
+  const double c1x = ((xnum1 + xnum2) / den + a) - xp, c1y = ((ynum1 - ynum2) / den + b) - yp;
+  const double c2x = ((xnum1 - xnum2) / den + a) - xp, c2y = ((ynum1 + ynum2) / den + b) - yp;
+  const double x11 = c1x * v1 - c1y * v0, x12 = c1x * c2y - c1y * c2x;
+  const double x21 = c2x * v1 - c2y * v0, x22 = c2x * c1y - c2y * c1x;
+  if (!(x11 * x12 >= 0 && x21 * x22 >= 0)) return INFINITY;
+  if (fabs(v0) < 1e-5 && fabs(v1) < 1e-5) return INFINITY;
+  const double px = hx, py = hy;
+  double x1, x2, y1, y2;
+  if (fabs(v0) < 1e-5) {
+    x1 = x2 = px;
+    const double A = 1, B = -2 * b, Cc = b * b + (px - a) * (px - a) - r * r;
+    y1 = (-B + sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    y2 = (-B - sqrt(B * B - 4 * A * Cc)) / (2 * A);
+  } else {
+    const double m = v1 / v0;
+    const double A = 1 + m * m;
+    const double B = -2 * a + 2 * m * (py - b - m * px);
+    const double Cc = a * a - r * r + (m * px - (py - b)) * (m * px - (py - b));
+    x1 = (-B + sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    x2 = (-B - sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    y1 = m * (x1 - px) + py;
+    y2 = m * (x2 - px) + py;
+  }
+  const double d1 = sqrt((x1 - px) * (x1 - px) + (y1 - py) * (y1 - py));
+  const double d2 = sqrt((x2 - px) * (x2 - px) + (y2 - py) * (y2 - py));
+  const double d = d2 < d1 ? d2 : d1;
+  return d / sqrt(v0 * v0 + v1 * v1);
+}
+
 // ---------------------------------------------------------------- main kernel
 // Work decomposition of one tile (ROW = 64 agent slots = floor(64/N) whole envs) on a workgroup of NT threads:
 //   agent phases  (A*): one LANE per agent, on wave 0 only -- the serial per-agent chains (incremental LP,
@@ -303,9 +344,10 @@ __host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>
 __host__ __device__ inline size_t lds_orca_bytes(int N) {
   return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * 2 * (N > 1 ? N - 1 : 1) * 16;
 }
-// union, sensor view: key / p_orth / dist_2_other / gap [N][ROW] f64, rank [N][ROW] i32, obs staging [ROW*W] f32
+// union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] i32,
+// obs staging [ROW*W] f32
 __host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage) {
-  return static_cast<size_t>(ROW) * N * (4 * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
+  return static_cast<size_t>(ROW) * N * (5 * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
 }
 
 struct Lane {  // per-lane registers of one agent (wave 0)
@@ -386,8 +428,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   double* omat = kmat + static_cast<size_t>(N) * ROW;    // [N][ROW] p_orth
   double* d2mat = omat + static_cast<size_t>(N) * ROW;   // [N][ROW] dist_2_other
   double* gmat = d2mat + static_cast<size_t>(N) * ROW;   // [N][ROW] centre distance - combined radius
-  int* rmat = reinterpret_cast<int*>(gmat + static_cast<size_t>(N) * ROW);  // [N][ROW] rank
-  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * (4 * 8 + 4));
+  double* tmat = gmat + static_cast<size_t>(N) * ROW;    // [N][ROW] time to impact (time_to_impact sorting only)
+  int* rmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(N) * ROW);  // [N][ROW] rank
+  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * (5 * 8 + 4));
 
   // ---- load my agent
   Lane r;
@@ -644,6 +687,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             d2o = d - hr - orad;
             key = rint(d2o * 100.0);  // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100
             po = rx * (-sh_pry[ag]) + ry * sh_prx[ag];
+            if (p.sort_mode == CA_SORT_TIME_TO_IMPACT)  // sensor :96-104
+              tmat[j * ROW + ag] = time_to_impact(hx, hy, ox, oy, sh_vx[ag], sh_vy[ag], sh_vx[eb + j], sh_vy[eb + j],
+                                                  hr + orad);
           }
         }
         kmat[j * ROW + ag] = key;
@@ -704,10 +750,23 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
         const double kj = kmat[j * ROW + ag], oj = omat[j * ROW + ag];
         int rank = 0, cnt = 0;
-        for (int q = 0; q < N; ++q) {
-          const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-          rank += (kq < kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0);
-          cnt += (kq < INFINITY) ? 1 : 0;
+        if (p.sort_mode == CA_SORT_TIME_TO_IMPACT) {  // key (-tti, -dist, p_orth), sensor :36-38
+          const bool vj = kj < INFINITY;
+          const double tj = vj ? tmat[j * ROW + ag] : 0.0;
+          for (int q = 0; q < N; ++q) {
+            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+            const bool vq = kq < INFINITY;
+            const double tq = vq ? tmat[q * ROW + ag] : 0.0;
+            const int before = (tq > tj) ? 1 : ((tq == tj) ? ((kq > kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0)) : 0);
+            rank += (vq && vj) ? before : 0;
+            cnt += vq ? 1 : 0;
+          }
+        } else {
+          for (int q = 0; q < N; ++q) {
+            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+            rank += (kq < kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0);
+            cnt += (kq < INFINITY) ? 1 : 0;
+          }
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
         float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
@@ -943,8 +1002,8 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   if (p->num_agents > 64) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 64 not supported yet (ORCA line tile must fit the 160 KiB LDS)%s");
   if (p->max_obs < 0) return fail(CA_EINVAL, "cagpu: max_obs < 0%s");
   if (p->obs_clip < 0 || p->obs_clip > p->max_obs) return fail(CA_EINVAL, "cagpu: obs_clip must be in [0, max_obs]%s");
-  if (p->sort_mode != CA_SORT_CLOSEST_FIRST && p->sort_mode != CA_SORT_CLOSEST_LAST)
-    return fail(CA_EUNSUPPORTED, "cagpu: only closest_first / closest_last sorting is implemented%s");
+  if (p->sort_mode < CA_SORT_CLOSEST_FIRST || p->sort_mode > CA_SORT_TIME_TO_IMPACT)
+    return fail(CA_EINVAL, "cagpu: unknown sort_mode (OtherAgentsStatesSensor.py:52 raises ValueError)%s");
   if (p->game_over_mode < 0 || p->game_over_mode > 2) return fail(CA_EINVAL, "cagpu: bad game_over_mode%s");
   if (!(p->dt > 0.0)) return fail(CA_EINVAL, "cagpu: dt must be > 0%s");
   if (!o->obs || !o->rewards || !o->done || !o->game_over) return fail(CA_EINVAL, "cagpu: NULL output pointer%s");
@@ -1035,7 +1094,7 @@ int launch_g16(const KArgs& k, hipStream_t st) {
 int launch_any(const KArgs& k, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = k.p.num_agents;
-  if (N <= G16 && std::getenv("CAGPU_G16")) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
+  if (N <= G16 && std::getenv("CAGPU_G16") && k.p.sort_mode != CA_SORT_TIME_TO_IMPACT) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
     const bool multi = k.mode == MODE_STEP && k.n_steps > 1;
     if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
     return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);

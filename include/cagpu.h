@@ -66,7 +66,7 @@ enum {
   CA_DYN_EXTERNAL = 2       /* dynamics/ExternalDynamics.py                  */
 };
 /* OtherAgentsStatesSensor.agent_sorting_method (sensors/OtherAgentsStatesSensor.py:34-52) */
-enum { CA_SORT_CLOSEST_FIRST = 0, CA_SORT_CLOSEST_LAST = 1, CA_SORT_TIME_TO_IMPACT = 2 /* not yet */ };
+enum { CA_SORT_CLOSEST_FIRST = 0, CA_SORT_CLOSEST_LAST = 1, CA_SORT_TIME_TO_IMPACT = 2 };
 /* game_over rule (collision_avoidance_env.py:537-551) */
 enum { CA_OVER_ALL_DONE = 0 /* EVALUATE_MODE */, CA_OVER_AGENT0 = 1 /* TRAIN_SINGLE_AGENT */, CA_OVER_LEARNING_DONE = 2 };
 

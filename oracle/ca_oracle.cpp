@@ -72,8 +72,49 @@ inline Ego ego_frame(double px, double py, double gx, double gy, double heading)
 
 struct Cand {
   int j;
-  double key, p_orth;
+  double key, p_orth, tti;
 };
+
+// util.py:101-127 tangent_vecs_from_external_pt + util.py:23-83 compute_time_to_impact (float64, numpy order)
+inline double time_to_impact(double hx, double hy, double ox, double oy, double hvx, double hvy, double ovx, double ovy,
+                             double r) {
+  const double v0 = hvx - ovx, v1 = hvy - ovy;  // v_rel
+  const double xp = hx, yp = hy, a = ox, b = oy;
+  const double sq = (xp - a) * (xp - a) + (yp - b) * (yp - b) - r * r;
+  if (sq < 0) return 0.0;  // already inside the collision zone
+  const double st = std::sqrt(sq);
+  const double xnum1 = r * r * (xp - a), xnum2 = r * (yp - b) * st;
+  const double ynum1 = r * r * (yp - b), ynum2 = r * (xp - a) * st;
+  const double den = (xp - a) * (xp - a) + (yp - b) * (yp - b);
+  const double c1x = ((xnum1 + xnum2) / den + a) - xp, c1y = ((ynum1 - ynum2) / den + b) - yp;
+  const double c2x = ((xnum1 - xnum2) / den + a) - xp, c2y = ((ynum1 + ynum2) / den + b) - yp;
+  const double x11 = c1x * v1 - c1y * v0, x12 = c1x * c2y - c1y * c2x;  // np.cross
+  const double x21 = c2x * v1 - c2y * v0, x22 = c2x * c1y - c2y * c1x;
+  const double inf = std::numeric_limits<double>::infinity();
+  if (!(x11 * x12 >= 0 && x21 * x22 >= 0)) return inf;
+  if (std::fabs(v0) < 1e-5 && std::fabs(v1) < 1e-5) return inf;
+  const double px = hx, py = hy;
+  double x1, x2, y1, y2;
+  if (std::fabs(v0) < 1e-5) {  // vertical v_rel
+    x1 = x2 = px;
+    const double A = 1, B = -2 * b, Cc = b * b + (px - a) * (px - a) - r * r;
+    y1 = (-B + std::sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    y2 = (-B - std::sqrt(B * B - 4 * A * Cc)) / (2 * A);
+  } else {
+    const double m = v1 / v0;
+    const double A = 1 + m * m;
+    const double B = -2 * a + 2 * m * (py - b - m * px);
+    const double Cc = a * a - r * r + (m * px - (py - b)) * (m * px - (py - b));
+    x1 = (-B + std::sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    x2 = (-B - std::sqrt(B * B - 4 * A * Cc)) / (2 * A);
+    y1 = m * (x1 - px) + py;
+    y2 = m * (x2 - px) + py;
+  }
+  const double d1 = std::sqrt((x1 - px) * (x1 - px) + (y1 - py) * (y1 - py));
+  const double d2 = std::sqrt((x2 - px) * (x2 - px) + (y2 - py) * (y2 - py));
+  const double d = d2 < d1 ? d2 : d1;  // min(d1, d2)
+  return d / std::sqrt(v0 * v0 + v1 * v1);
+}
 
 // OtherAgentsStatesSensor.py:58-144 for host `a` of env `e` -> one obs row, written at `row`
 void sense(const OrcParams& p, const OrcState& s, int e, int a, double* row) {
@@ -90,14 +131,26 @@ void sense(const OrcParams& p, const OrcState& s, int e, int a, double* row) {
     const double dc = std::sqrt(rx * rx + ry * ry);  // util.py:148-153
     const double d2o = dc - s.radius[h] - s.radius[o];
     if (dc > p.sensing_horizon) continue;  // :90
-    Cand k = {j, round2(d2o), p_orth};
+    double tti = 0.0;
+    if (p.sort_mode == ORC_SORT_TIME_TO_IMPACT)  // :96-104
+      tti = time_to_impact(s.pos_x[h], s.pos_y[h], s.pos_x[o], s.pos_y[o], s.vel_x[h], s.vel_y[h], s.vel_x[o],
+                           s.vel_y[o], s.radius[h] + s.radius[o]);
+    Cand k = {j, round2(d2o), p_orth, tti};
     c.push_back(k);
   }
-  // :34-52 (time_to_impact is a "next" row: not restated yet)
-  std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) {
-    if (x.key != y.key) return x.key < y.key;
-    return x.p_orth < y.p_orth;
-  });
+  // :34-52
+  if (p.sort_mode == ORC_SORT_TIME_TO_IMPACT) {  // key (-tti, -dist, p_orth) for the clip and for the final order
+    std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) {
+      if (-x.tti != -y.tti) return -x.tti < -y.tti;
+      if (-x.key != -y.key) return -x.key < -y.key;
+      return x.p_orth < y.p_orth;
+    });
+  } else {
+    std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) {
+      if (x.key != y.key) return x.key < y.key;
+      return x.p_orth < y.p_orth;
+    });
+  }
   const int clip = p.obs_clip < K ? p.obs_clip : K;  // :39 clip to the sensor's own limit; rows stay K (:112)
   if (static_cast<int>(c.size()) > clip) c.resize(clip);
   if (p.sort_mode == ORC_SORT_CLOSEST_LAST) {
@@ -382,14 +435,12 @@ int ca_oracle_reset(const OrcParams* p, const OrcState* s, const OrcOut* o, cons
 }
 
 int ca_oracle_step(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions) {
-  if (p->sort_mode == ORC_SORT_TIME_TO_IMPACT) return -1;
   for (int e = 0; e < p->num_envs; ++e) step_env(*p, *s, *o, ext_actions, e);
   return 0;
 }
 
 int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* table, int32_t n_cases,
                       int64_t env_id_offset, int64_t case_stride, int32_t n_steps) {
-  if (p->sort_mode == ORC_SORT_TIME_TO_IMPACT) return -1;
   const int N = p->num_agents;
   for (int t = 0; t < n_steps; ++t)
     for (int e = 0; e < p->num_envs; ++e) {

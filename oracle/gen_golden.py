@@ -42,6 +42,8 @@ SCENARIOS = {
     "noncoop10": dict(cfg="Bench10", kind="fixture", n=10, cases=[4, 5], policy="noncoop", max_steps=400),
     # K < N-1 with closest_last ordering
     "clip6_rvo": dict(cfg="Clip6", kind="fixture", n=6, cases=[0, 1], policy="RVO", max_steps=400),
+    # time_to_impact ordering (util.py:23-127) with K < N-1
+    "tti6_rvo": dict(cfg="Tti6", kind="fixture", n=6, cases=[2, 3], policy="RVO", max_steps=400),
     # K > N-1, mixed policies / dynamics, a head-on collision, a static agent, an externally driven learner
     "mixed5": dict(cfg="Pad5", kind="mixed", max_steps=120),
     # training-mode rules (DT=0.2, MAX_TIME_RATIO=2 -> time-outs; game over when the learner is done)

@@ -50,6 +50,12 @@ class Clip6(_Eval):         # K < N-1 (clipping) and closest_last ordering
     SORT = "closest_last"
 
 
+class Tti6(_Eval):         # time_to_impact ordering, K < N-1
+    N_MAX = 6
+    K = 4
+    SORT = "time_to_impact"
+
+
 class Pad5(_Eval):          # K > N-1 (zero padding), 5 agents in a 8-slot env
     N_MAX = 5
     K = 7

@@ -41,6 +41,10 @@ class Clip6(_Eval):
     N_MAX, K, SORT = 6, 3, "closest_last"
 
 
+class Tti6(_Eval):
+    N_MAX, K, SORT = 6, 4, "time_to_impact"
+
+
 class Pad5(_Eval):
     N_MAX, K = 5, 7
 

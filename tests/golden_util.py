@@ -11,7 +11,7 @@ DATA = os.path.join(os.path.dirname(GOLD), "..", "gym_collision_avoidance_amd", 
 # columns of the recorded per-agent state (oracle/gen_golden.py:_snapshot)
 COLS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
         "time_remaining", "t", "slt", "act0", "act1", "step_num")
-SCENARIOS = ("rvo10", "rvo4_swap", "rvo3", "noncoop10", "clip6_rvo", "mixed5", "train5")
+SCENARIOS = ("rvo10", "rvo4_swap", "rvo3", "noncoop10", "clip6_rvo", "tti6_rvo", "mixed5", "train5")
 
 
 class Episode(object):

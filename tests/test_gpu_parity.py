@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 MASK = 0x3F
-SORT = {"closest_first": 0, "closest_last": 1}
+SORT = {"closest_first": 0, "closest_last": 1, "time_to_impact": 2}
 F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
        "time_remaining", "t", "slt", "ep_reward")
 
@@ -158,6 +158,30 @@ def test_reinjected_vs_oracle_fixtures(N, E, steps):
         _compare(o, g, what="N=%d step %d" % (N, t))
         np.testing.assert_allclose(g.state["env_stats"].cpu().numpy(), o.s["env_stats"], rtol=0, atol=1e-6)
     assert o.s["env_stats"][:, 0].sum() > 0 or steps < 100  # some episodes ended -> auto-reset path exercised
+
+
+@pytest.mark.parametrize("N,E,K", [(6, 200, 4), (10, 300, 9), (20, 40, 19)])
+def test_time_to_impact_sorting_vs_oracle(N, E, K):
+    """agent_sorting_method = time_to_impact (util.py:23-127), re-injected each step, mixed velocities"""
+    nat, core, orc = _mods()
+    rng = np.random.default_rng(N)
+    o, g = _pair(E, N, K, sort_mode=2)
+    pol = np.where(rng.random((E, N)) < 0.7, orc.POL_RVO, orc.POL_NONCOOP).astype(np.int32)
+    o.s["policy"][:] = pol.reshape(-1)
+    g.set_plugins(pol)
+    cases = np.zeros((E, N, 6))
+    cases[..., 0:2] = rng.uniform(-6, 6, (E, N, 2))
+    cases[..., 2:4] = rng.uniform(-6, 6, (E, N, 2))
+    cases[..., 4] = rng.uniform(0.5, 2.0, (E, N))
+    cases[..., 5] = rng.uniform(0.2, 0.6, (E, N))
+    o.reset(cases)
+    g.reset(cases)
+    _compare_reset(o, g)
+    for t in range(60):
+        _upload(o, g)
+        o.step()
+        g.step()
+        _compare(o, g, what="tti N=%d step %d" % (N, t))
 
 
 def _compare_reset(o, g):

@@ -11,7 +11,8 @@ from oracle import ca_oracle as orc
 from tests import golden_util as gu
 
 TOL = 1e-5
-SORT = {"closest_first": orc.SORT_CLOSEST_FIRST, "closest_last": orc.SORT_CLOSEST_LAST}
+SORT = {"closest_first": orc.SORT_CLOSEST_FIRST, "closest_last": orc.SORT_CLOSEST_LAST,
+        "time_to_impact": orc.SORT_TIME_TO_IMPACT}
 MASK = 0x3F  # the six agent-state flags
 # mixed5 holds a UnicycleDynamicsMaxTurnRate agent: under numpy>=2 (NEP 50) the reference evaluates
 # `action[1]/dt` (UnicycleDynamicsMaxTurnRate.py:31) in float32 because action[1] is an np.float32 scalar and dt
