@@ -346,8 +346,8 @@ __host__ __device__ inline size_t lds_orca_bytes(int N) {
 }
 // union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] i32,
 // obs staging [ROW*W] f32
-__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage) {
-  return static_cast<size_t>(ROW) * N * (5 * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
+__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti) {
+  return static_cast<size_t>(ROW) * N * ((tti ? 5 : 4) * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
 }
 
 struct Lane {  // per-lane registers of one agent (wave 0)
@@ -428,9 +428,10 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   double* omat = kmat + static_cast<size_t>(N) * ROW;    // [N][ROW] p_orth
   double* d2mat = omat + static_cast<size_t>(N) * ROW;   // [N][ROW] dist_2_other
   double* gmat = d2mat + static_cast<size_t>(N) * ROW;   // [N][ROW] centre distance - combined radius
+  const int has_tti = (p.sort_mode == CA_SORT_TIME_TO_IMPACT) ? 1 : 0;
   double* tmat = gmat + static_cast<size_t>(N) * ROW;    // [N][ROW] time to impact (time_to_impact sorting only)
-  int* rmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(N) * ROW);  // [N][ROW] rank
-  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * (5 * 8 + 4));
+  int* rmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(has_tti ? N : 0) * ROW);  // [N][ROW] rank
+  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * ((has_tti ? 5 : 4) * 8 + 4));
 
   // ---- load my agent
   Lane r;
@@ -1046,11 +1047,12 @@ template <int NT>
 int launch_main(const KArgs& k, hipStream_t st) {
   const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
   const size_t un_orca = lds_orca_bytes(N);
-  size_t un_sense = lds_sense_bytes(N, W, 1);
+  const int tti = k.p.sort_mode == CA_SORT_TIME_TO_IMPACT ? 1 : 0;
+  size_t un_sense = lds_sense_bytes(N, W, 1, tti);
   bool stage = true;
   size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   if (total > 64 * 1024) {  // keep >= 2 workgroups per CU when possible: give up the staging area first
-    un_sense = lds_sense_bytes(N, W, 0);
+    un_sense = lds_sense_bytes(N, W, 0, tti);
     stage = false;
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
