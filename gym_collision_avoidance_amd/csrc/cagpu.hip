@@ -333,6 +333,7 @@ constexpr int ROW = 64;
 #ifdef CAGPU_ABLATE
 #define AB(bit) (k.ablate & (bit))
 __device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_wgprof[1024 * 16];
 #define TICK(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); sh_prof[slot] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else
 #define AB(bit) false
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       }
       TICK(3);
       // ================= A2c: policy post-processing (env.py:305-323) and move (agent.py:192-241), one lane per agent
+      TICK(0);
       if (wave0) {
         double spd = 0.0, dh = 0.0;
         if (query) {
@@ -616,9 +618,12 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
             const float npx = sh_fpx[lane] + v.x * ts, npy = sh_fpy[lane] + v.y * ts;
             const double dpx = static_cast<double>(npx) - r.px, dpy = static_cast<double>(npy) - r.py;
+            TICK(15);
             const double ang = AB(4) ? dpy : atan2(dpy, dpx);
+            TICK(13);
             const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
             dh = wrap_pi(nh - r.heading);
+            TICK(14);
             spd = (1.0 / p.dt) * sqrt(dpx * dpx + dpy * dpy);
             if (fabs(dh) > kPi / 6) {
               dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
@@ -958,6 +963,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
 #ifdef CAGPU_ABLATE
   __syncthreads();
   if (tid < 16) atomicAdd(&g_prof[tid], sh_prof[tid]);
+  if (tid < 16 && blockIdx.x < 1024) g_wgprof[blockIdx.x * 16 + tid] = sh_prof[tid];
 #endif
   // ---- store my agent.  The pointers are re-read from the kernarg segment here (laundered so the compiler does
   // not keep 19 pointer pairs alive in SGPRs across the whole kernel).
@@ -1233,6 +1239,11 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
 }
 
 #ifdef CAGPU_ABLATE
+int cagpu_debug_wgprof(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgprof), sizeof(unsigned long long) * 1024 * 16);
+  return 0;
+}
 int cagpu_debug_prof(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
