@@ -341,8 +341,8 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 #endif
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
-// fixed: 10 f64 + 8 f32 + 5 u32 per agent slot (+ one counter word, padded to 16 B)
-__host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 8 * 4 + 5 * 4) + 16; }
+// fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
+__host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 10 * 4 + 4 * 4); }
 // union, ORCA view: dist^2 [N][ROW] f32, lines + projected lines [N-1][ROW] float4 each
 __host__ __device__ inline size_t lds_orca_bytes(int N) {
   return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * 2 * (N > 1 ? N - 1 : 1) * 16;
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   int* sh_q = reinterpret_cast<int*>(sh_flag + ROW);  // 1: this agent queries ORCA this step
   int* sh_nb = sh_q + ROW;                            // its neighbour count n
   int* sh_sense = sh_nb + ROW;                        // 1: (re)write this agent's observation in this pass
-  float* sh_vrx = reinterpret_cast<float*>(sh_sense + ROW);  // ORCA velocity of each agent (LP2 result, then LP3's)
+  float* sh_vrx = reinterpret_cast<float*>(sh_sense + ROW);  // ORCA velocity of each agent
   float* sh_vry = sh_vrx + ROW;
   float* sh_fms = sh_vry + ROW;                       // its speed limit (float pref_speed)
-  int* sh_flist = reinterpret_cast<int*>(sh_fms + ROW);  // agents whose LP2 was infeasible: agent | first failing line << 8
-  int* sh_nflag = sh_flist + ROW;                     // how many
+  float* sh_fprx = sh_fms + ROW;                      // its preferred velocity (float)
+  float* sh_fpry = sh_fprx + ROW;
   unsigned char* un = smem + lds_fixed_bytes();
   // ORCA view of the union
   float* dmat = reinterpret_cast<float*>(un);                                   // [N][ROW]
@@ -510,7 +510,13 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         sh_fvy[lane] = static_cast<float>(r.vy);
         sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
         sh_q[lane] = rvo ? 1 : 0;
-        if (lane == 0) *sh_nflag = 0;
+        if (rvo) {
+          const double vx = r.gx - r.px, vy = r.gy - r.py;
+          const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
+          sh_fprx[lane] = static_cast<float>(sc * vx);
+          sh_fpry[lane] = static_cast<float>(sc * vy);
+          sh_fms[lane] = static_cast<float>(r.ps);
+        }
       }
       const int any_rvo = __syncthreads_or(rvo ? 1 : 0);
       TICK(1);
@@ -560,52 +566,41 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       }
 
       TICK(2);
-      // ================= A2a (wave 0): linearProgram2, one lane per agent, serial over its lines
-      const bool coop_lp3 = N <= G16;  // the 16-lane-group LP3 needs at most 15 lines per agent
-      if (wave0 && query && pol == CA_POL_RVO) {
-        const double vx = r.gx - r.px, vy = r.gy - r.py;
-        const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
-        const F2 pref = f2(static_cast<float>(sc * vx), static_cast<float>(sc * vy));
-        const float ms = static_cast<float>(r.ps);
-        const int n = sh_nb[lane];
-        F2 v;
-        int fail = n;
-        if (AB(2)) v = pref; else fail = lp2<ROW>(Lmat + lane, n, ms, pref, false, v);
-#ifdef CAGPU_ABLATE
-        if (fail < n) atomicAdd(&g_prof[14], 1ull);
-        atomicAdd(&g_prof[15], 1ull);
-#endif
-        if (fail < n) {
-          if (coop_lp3) {  // hand the agent to a 16-lane group (4.6 % of the queries, but 94 % of the 60-agent tiles)
-            const int slot = atomicAdd(sh_nflag, 1);
-            sh_flist[slot] = lane | (fail << 8);
-            sh_fms[lane] = ms;
-          } else {
-            lp3<ROW>(Lmat + lane, Pmat + lane, n, fail, ms, v);
+      // ================= A2a: the ORCA linear program.
+      //   N <= 16: solved by 16-lane groups of EVERY wave, one lane per half-plane (cagpu_grouplp.inc): linearProgram2
+      //            costs O(#violated lines) group steps instead of a serial O(n^2) walk through LDS, and the 4.6 % of
+      //            queries that fall through to linearProgram3 (94 % of the 60-agent tiles hold at least one) no
+      //            longer stall the other 59 lanes of a wave;
+      //   N  > 16: one lane per agent on wave 0, serial over its lines in LDS.
+      if (N <= G16) {
+        if (any_rvo && !AB(2)) {
+          const int jl = tid & 15;
+          for (int agf = tid >> 4; agf < tile_n; agf += NT / 16) {
+            if (!sh_q[agf]) continue;
+            const int nf = sh_nb[agf];
+            const bool valid = jl < nf;
+            const float4 ln = Lmat[(valid ? jl : 0) * ROW + agf];
+            const F2 P = f2(ln.x, ln.y), D = f2(ln.z, ln.w);
+            const float ms = sh_fms[agf];
+            F2 v;
+            const int failf = lp2_group(valid, P, D, ms, f2(sh_fprx[agf], sh_fpry[agf]), false, v, jl, tid & 63);
+            if (failf != NOFAIL) lp3_group(nf, failf, P, D, ms, v, jl, tid & 63);
+            if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
           }
         }
+        __syncthreads();
+      } else if (wave0 && rvo) {
+        const F2 pref = f2(sh_fprx[lane], sh_fpry[lane]);
+        const float ms = sh_fms[lane];
+        const int n = sh_nb[lane];
+        F2 v;
+        const int fail = lp2<ROW>(Lmat + lane, n, ms, pref, false, v);
+        if (fail < n) lp3<ROW>(Lmat + lane, Pmat + lane, n, fail, ms, v);
         sh_vrx[lane] = v.x;
         sh_vry[lane] = v.y;
       }
+      if (N > G16) __syncthreads();
       TICK(12);
-      // ================= A2b (16-lane groups of every wave): linearProgram3 of the flagged agents, one lane per line
-      if (coop_lp3) {
-        __syncthreads();
-        const int nflag = *sh_nflag;
-        if (nflag > 0) {
-          const int jl = tid & 15;
-          for (int f = tid >> 4; f < nflag; f += NT / 16) {
-            const int code = sh_flist[f];
-            const int agf = code & 0xFF, failf = code >> 8;
-            const int nf = sh_nb[agf];
-            const float4 ln = Lmat[(jl < nf ? jl : 0) * ROW + agf];
-            F2 vres = f2(sh_vrx[agf], sh_vry[agf]);
-            lp3_group(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], vres, jl, tid & 63);
-            if (jl == 0) { sh_vrx[agf] = vres.x; sh_vry[agf] = vres.y; }
-          }
-          __syncthreads();
-        }
-      }
       TICK(3);
       // ================= A2c: policy post-processing (env.py:305-323) and move (agent.py:192-241), one lane per agent
       TICK(0);
