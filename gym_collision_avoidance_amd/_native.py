@@ -46,8 +46,19 @@ class CaAutoReset(C.Structure):
     _fields_ = [("table", _P), ("n_cases", C.c_int32), ("env_id_offset", C.c_int64), ("case_stride", C.c_int64)]
 
 
-EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_rollout", "cagpu_orca",
-           "cagpu_observe")
+class CaMap(C.Structure):
+    _fields_ = [("static_bits", _P), ("rows", C.c_int32), ("cols", C.c_int32), ("cell", C.c_double),
+                ("origin_r", C.c_double), ("origin_c", C.c_double)]
+
+
+class CaScan(C.Structure):
+    _fields_ = [("hist", _P), ("out", _P), ("num_beams", C.c_int32), ("num_to_store", C.c_int32),
+                ("num_ranges", C.c_int32), ("reserved0", C.c_int32), ("min_angle", C.c_double),
+                ("max_angle", C.c_double), ("range_res", C.c_double), ("max_range", C.c_double)]
+
+
+EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan")
 
 _lib = None
 
@@ -71,6 +82,8 @@ def lib():
     L.cagpu_reset.argtypes = [PP, PS, PO, _P, _P, _P, _P]
     L.cagpu_step.argtypes = [PP, PS, PO, _P, PA, _P]
     L.cagpu_rollout.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
+    L.cagpu_step_map.argtypes = [PP, PS, PO, _P, PA, C.POINTER(CaMap), _P]
+    L.cagpu_laserscan.argtypes = [PP, PS, C.POINTER(CaMap), C.POINTER(CaScan), _P]
     L.cagpu_observe.argtypes = [PP, PS, PO, _P]
     L.cagpu_orca.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int32,
                              C.c_float, _P, _P]

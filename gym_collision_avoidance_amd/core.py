@@ -74,6 +74,9 @@ class BatchedSim(object):
         self._ar = None
         self._table = None
         self._keep = []
+        self._map = None
+        self._scan = None
+        self.scan = None
 
     # ---------------------------------------------------------------- plumbing
     def _stream(self):
@@ -133,13 +136,51 @@ class BatchedSim(object):
         idx = (torch.arange(self.E, device=self.device) + off) % self._table.shape[0]
         return self.reset(self._table[idx])
 
+    def set_map(self, static_map=None, rows=160, cols=160, cell=0.1, num_beams=512, num_to_store=3, max_range=6.0,
+                range_res=0.1, min_angle=-math.pi / 2, max_angle=math.pi / 2):
+        """Static occupancy grid (Map.py:6-24; bool [rows, cols], True = occupied, or None for an empty map) + the
+        LaserScanSensor buffers with the reference's hard-coded parameters (LaserScanSensor.py:28-39).  With a map
+        set, step() also tests wall collisions (collision_avoidance_env.py:494-506)."""
+        bits = None
+        if static_map is not None:
+            m = np.asarray(static_map).astype(bool)
+            assert m.shape == (rows, cols), m.shape
+            wpr = (cols + 31) // 32
+            pad = np.zeros((rows, wpr * 32), dtype=np.uint8)
+            pad[:, :cols] = m
+            words = np.packbits(pad.reshape(rows, wpr, 32), axis=-1, bitorder="little").view(np.uint32).reshape(rows, wpr)
+            bits = torch.from_numpy(words.view(np.int32).copy()).to(self.device)
+        self._map_bits = bits
+        self._map = nat.CaMap(static_bits=None if bits is None else bits.data_ptr(), rows=rows, cols=cols, cell=cell,
+                              origin_r=(rows * cell / 2.) / cell, origin_c=(cols * cell / 2.) / cell)
+        R = len(np.arange(0, max_range, range_res))
+        self.scan_hist = torch.full((self.E, self.N, num_to_store, num_beams), 255, dtype=torch.uint8,
+                                    device=self.device)
+        self.scan = torch.zeros((self.E, self.N, num_to_store, num_beams), dtype=torch.float32, device=self.device)
+        self._scan = nat.CaScan(hist=self.scan_hist.data_ptr(), out=self.scan.data_ptr(), num_beams=num_beams,
+                                num_to_store=num_to_store, num_ranges=R, min_angle=min_angle, max_angle=max_angle,
+                                range_res=range_res, max_range=max_range)
+
+    def laserscan(self):
+        """'laserscan' observation [E,N,num_to_store,num_beams] of the current state (call after reset / step)."""
+        assert self._map is not None, "set_map() first"
+        nat.check(self.lib.cagpu_laserscan(C.byref(self.p), C.byref(self._cs), C.byref(self._map),
+                                           C.byref(self._scan), self._stream()))
+        return self.scan
+
     def step(self, ext_actions=None):
         e = self._dev(ext_actions, torch.float64)
         if e is not None:
             assert tuple(e.shape) == (self.E, self.N, 2), e.shape
-        nat.check(self.lib.cagpu_step(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
-                                      None if e is None else e.data_ptr(),
-                                      None if self._ar is None else C.byref(self._ar), self._stream()))
+        if self._map is not None:
+            nat.check(self.lib.cagpu_step_map(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
+                                              None if e is None else e.data_ptr(),
+                                              None if self._ar is None else C.byref(self._ar), C.byref(self._map),
+                                              self._stream()))
+        else:
+            nat.check(self.lib.cagpu_step(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
+                                          None if e is None else e.data_ptr(),
+                                          None if self._ar is None else C.byref(self._ar), self._stream()))
         self._keep = [e]
         return self.obs, self.rewards, self.game_over
 

@@ -53,6 +53,7 @@ struct KArgs {
   const double* reset_cases;
   const double* reset_headings;
   const uint8_t* reset_mask;
+  CaMap map;  // static obstacles for wall collisions (static_bits == NULL: none)
   int32_t n_steps, mode, stage_obs;
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
@@ -341,6 +342,8 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 #endif
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
+#include "cagpu_scan.inc"
+
 // fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
 __host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 10 * 4 + 4 * 4); }
 // union, ORCA view: dist^2 [N][ROW] f32, lines + projected lines [N-1][ROW] float4 each
@@ -758,6 +761,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             if (coll) {
               rw = p.reward_collision;
               r.flags |= CA_IN_COLLISION;
+            } else if (hits_wall(k.map, r.px, r.py, r.rad)) {  // env.py:425-429, :494-506 (same reward value)
+              rw = p.reward_collision;
+              r.flags |= CA_IN_COLLISION;
             } else {
               if (nearest <= p.getting_close_range) rw = -0.1 - nearest / 2.0;
               if (fabs(static_cast<double>(r.act1)) > p.wiggly_threshold) rw += p.reward_wiggly;
@@ -1138,7 +1144,7 @@ int launch_g16(const KArgs& k, hipStream_t st) {
 int launch_any(const KArgs& k, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = k.p.num_agents;
-  if (N <= G16 && std::getenv("CAGPU_G16") && k.p.sort_mode != CA_SORT_TIME_TO_IMPACT) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
+  if (N <= G16 && std::getenv("CAGPU_G16") && k.p.sort_mode != CA_SORT_TIME_TO_IMPACT && !k.map.static_bits) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
     const bool multi = k.mode == MODE_STEP && k.n_steps > 1;
     if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
     return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);
@@ -1195,7 +1201,7 @@ int cagpu_reset(const CaParams* p, const CaState* s, const CaOut* o, const doubl
 }
 
 static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const double* ext, const CaAutoReset* ar,
-                     int32_t n_steps, void* stream) {
+                     int32_t n_steps, void* stream, const CaMap* map = nullptr) {
   int rc = check_params(p, s, o);
   if (rc) return rc;
   if (n_steps < 1) return fail(CA_EINVAL, "cagpu: n_steps must be >= 1%s");
@@ -1205,6 +1211,10 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
   if (ar) {
     if (!ar->table || ar->n_cases < 1) return fail(CA_EINVAL, "cagpu: bad CaAutoReset%s");
     k.table = ar->table; k.n_cases = ar->n_cases; k.env_id_offset = ar->env_id_offset; k.case_stride = ar->case_stride;
+  }
+  if (map && map->static_bits) {
+    if (map->rows < 1 || map->cols < 1 || !(map->cell > 0.0)) return fail(CA_EINVAL, "cagpu: bad CaMap%s");
+    k.map = *map;
   }
   k.n_steps = n_steps; k.mode = MODE_STEP;
 #ifdef CAGPU_ABLATE
@@ -1216,6 +1226,37 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
 int cagpu_step(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,
                void* stream) {
   return step_impl(p, s, o, ext_actions, ar, 1, stream);
+}
+
+int cagpu_step_map(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,
+                   const CaMap* map, void* stream) {
+  return step_impl(p, s, o, ext_actions, ar, 1, stream, map);
+}
+
+int cagpu_laserscan(const CaParams* p, const CaState* s, const CaMap* map, const CaScan* scan, void* stream) {
+  if (!p || !s || !map || !scan) return fail(CA_EINVAL, "cagpu_laserscan: NULL argument%s");
+  if (p->num_envs < 1 || p->num_agents < 1 || p->num_agents > 256) return fail(CA_EINVAL, "cagpu_laserscan: bad sizes%s");
+  if (map->rows < 1 || map->cols < 1 || !(map->cell > 0.0)) return fail(CA_EINVAL, "cagpu_laserscan: bad CaMap%s");
+  if (!scan->hist || !scan->out || scan->num_beams < 2 || scan->num_to_store < 1 || scan->num_ranges < 1 ||
+      scan->num_ranges > 255)
+    return fail(CA_EINVAL, "cagpu_laserscan: bad CaScan%s");
+  if (!s->pos_x || !s->pos_y || !s->heading || !s->radius || !s->step_num) return fail(CA_EINVAL, "cagpu_laserscan: NULL state pointer%s");
+  ScanArgs k;
+  std::memset(&k, 0, sizeof(k));
+  k.p = *p; k.s = *s; k.m = *map; k.sc = *scan;
+  const int N = p->num_agents, wpr = (map->cols + 31) >> 5;
+  const size_t total = align16(static_cast<size_t>(map->rows) * wpr * 4) + static_cast<size_t>(N) * (4 * 8 + 2 * 8 + 3 * 4) + 16;
+  if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu_laserscan: map too large for the LDS bitmap%s");
+  if (total > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
+    if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(scan_kernel, dim3(static_cast<unsigned>(p->num_envs)), dim3(SCAN_NT), total,
+                     static_cast<hipStream_t>(stream), k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
 }
 
 int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,

@@ -130,6 +130,24 @@ typedef struct CaAutoReset {
   int64_t case_stride;   /* normally the global number of envs */
 } CaAutoReset;
 
+/* Static occupancy grid shared by every env (Map.py:6-24; the env builds Map(16 m, 16 m, 0.1 m), env.py:378-392).
+ * Bit-packed, row-major: cell (row, col) is bit (col & 31) of word static_bits[row * ((cols + 31) / 32) + col / 32];
+ * row = floor(origin_r - y / cell), col = floor(origin_c + x / cell) (Map.py:26-32). */
+typedef struct CaMap {
+  const uint32_t *static_bits; /* device; NULL = no static obstacles (agents are still rasterised for the scan) */
+  int32_t rows, cols;
+  double cell, origin_r, origin_c;
+} CaMap;
+
+/* LaserScanSensor state + observation (sensors/LaserScanSensor.py:24-44): num_beams beams over
+ * [min_angle, max_angle] around the heading, num_ranges samples every range_res metres. */
+typedef struct CaScan {
+  uint8_t *hist; /* device [E,N,num_to_store,num_beams]: range index per beam, 255 = nothing hit (state) */
+  float *out;    /* device [E,N,num_to_store,num_beams]: the 'laserscan' observation in metres */
+  int32_t num_beams, num_to_store, num_ranges, reserved0;
+  double min_angle, max_angle, range_res, max_range;
+} CaScan;
+
 int cagpu_version(void);
 const char *cagpu_last_error(void);
 
@@ -149,6 +167,19 @@ int cagpu_reset(const CaParams *p, const CaState *s, const CaOut *o, const doubl
  * (the reference's `env.step(None)`, env_utils.py:50).  ar == NULL: no auto-reset. */
 int cagpu_step(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions, const CaAutoReset *ar,
                void *stream);
+
+/* cagpu_step with a static map: an agent whose disc covers an occupied static cell collides with the wall
+ * (collision_avoidance_env.py:494-506, :425-429).  map == NULL or map->static_bits == NULL: same as cagpu_step. */
+int cagpu_step_map(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions, const CaAutoReset *ar,
+                   const CaMap *map, void *stream);
+
+/* Replaces: Map.add_agents_to_map (Map.py:46-64) + LaserScanSensor.sense (sensors/LaserScanSensor.py:49-101) for every
+ * agent of every env, on the CURRENT state (call after cagpu_reset / cagpu_step): the env's agents are rasterised as
+ * discs into a copy of the static grid held in LDS, every beam is marched through it (the agent's own disc is
+ * transparent), the result is the range of the last sample before the SECOND hit (the reference's
+ * `cumsum == 1` indexing, LaserScanSensor.py:77-81).  An agent with step_num == 0 takes its first measurement (all
+ * history rows filled, :84-85), otherwise the history is rolled (:86-88). */
+int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const CaScan *scan, void *stream);
 
 /* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
  * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is

@@ -215,7 +215,30 @@ void reset_env(const OrcParams& p, const OrcState& s, int e, const double* cs /*
   s.episode_step[e] = 0;
 }
 
-void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const double* ext, int e) {
+// Map.py:26-32 world_coordinates_to_map_indices
+inline void to_cell(const OrcMap& m, double x, double y, long& gr, long& gc, bool& in_map) {
+  gr = static_cast<long>(std::floor(m.origin_r - y / m.cell));
+  gc = static_cast<long>(std::floor(m.origin_c + x / m.cell));
+  in_map = gr >= 0 && gc >= 0 && gr < m.rows && gc < m.cols;
+}
+
+// env.py:494-506: does the agent's disc (Map.py:54-58 get_agent_map_indices) cover an occupied static cell?
+bool hits_wall(const OrcMap& m, double x, double y, double radius) {
+  if (!m.static_map) return false;
+  long gr, gc;
+  bool in_map;
+  to_cell(m, x, y, gr, gc, in_map);
+  if (!in_map) return false;
+  const double rr = (radius / m.cell) * (radius / m.cell);
+  for (long r = 0; r < m.rows; ++r)
+    for (long c = 0; c < m.cols; ++c) {
+      const double dc = static_cast<double>(c - gc), dr = static_cast<double>(r - gr);
+      if (dc * dc + dr * dr < rr && m.static_map[r * m.cols + c]) return true;
+    }
+  return false;
+}
+
+void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const double* ext, int e, const OrcMap* map = nullptr) {
   const int N = p.num_agents;
   const int b = e * N;
   s.episode_step[e] += 1;  // env.py:183
@@ -358,6 +381,9 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
       if (coll[a]) {
         r = p.reward_collision;
         f |= ORC_IN_COLLISION;
+      } else if (map && hits_wall(*map, s.pos_x[i], s.pos_y[i], s.radius[i])) {  // env.py:425-429
+        r = p.reward_collision;  // REWARD_COLLISION_WITH_WALL has the same value (config.py:32-33)
+        f |= ORC_IN_COLLISION;
       } else {
         if (nearest[a] <= p.getting_close_range) r = -0.1 - nearest[a] / 2.0;
         if (std::fabs(static_cast<double>(s.last_action[2 * i + 1])) > p.wiggly_threshold) r += p.reward_wiggly;
@@ -453,6 +479,77 @@ int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, co
         observe_env(*p, *s, *o, e);
       }
     }
+  return 0;
+}
+
+int ca_oracle_step_map(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions, const OrcMap* m) {
+  for (int e = 0; e < p->num_envs; ++e) step_env(*p, *s, *o, ext_actions, e, m);
+  return 0;
+}
+
+// Map.add_agents_to_map (Map.py:46-52) + LaserScanSensor.sense (LaserScanSensor.py:49-101)
+int ca_oracle_laserscan(const OrcParams* p, const OrcState* s, const OrcMap* m, const OrcScan* sc) {
+  const int N = p->num_agents, B = sc->num_beams, R = sc->num_ranges, H = sc->num_to_store;
+  std::vector<uint8_t> grid(static_cast<size_t>(m->rows) * m->cols);
+  std::vector<double> angles(B), ranges(R);
+  {  // np.linspace(min, max, B) and np.arange(0, max_range, res)
+    const double step = (sc->max_angle - sc->min_angle) / (B - 1);
+    for (int b = 0; b < B; ++b) angles[b] = b * step + sc->min_angle;
+    angles[B - 1] = sc->max_angle;
+    for (int r = 0; r < R; ++r) ranges[r] = 0.0 + r * sc->range_res;
+  }
+  for (int e = 0; e < p->num_envs; ++e) {
+    const int b0 = e * N;
+    if (m->static_map) std::copy(m->static_map, m->static_map + grid.size(), grid.begin());
+    else std::fill(grid.begin(), grid.end(), 0);
+    for (int a = 0; a < N; ++a) {  // rasterise every agent as a disc around its (floored) cell
+      long gr, gc;
+      bool in_map;
+      to_cell(*m, s->pos_x[b0 + a], s->pos_y[b0 + a], gr, gc, in_map);
+      if (!in_map) continue;
+      const double rr = (s->radius[b0 + a] / m->cell) * (s->radius[b0 + a] / m->cell);
+      for (long r = 0; r < m->rows; ++r)
+        for (long c = 0; c < m->cols; ++c) {
+          const double dc = static_cast<double>(c - gc), dr = static_cast<double>(r - gr);
+          if (dc * dc + dr * dr < rr) grid[r * m->cols + c] = 1;
+        }
+    }
+    for (int a = 0; a < N; ++a) {
+      const int i = b0 + a;
+      long er, ec;
+      bool ego_in;
+      to_cell(*m, s->pos_x[i], s->pos_y[i], er, ec, ego_in);
+      const double err = (s->radius[i] / m->cell) * (s->radius[i] / m->cell);
+      uint8_t* hist = sc->hist + static_cast<size_t>(i) * H * B;
+      const bool first = s->step_num[i] == 0;  // Sensor.num_measurements_made == 0
+      if (!first)
+        for (int h = H - 1; h > 0; --h) std::memcpy(hist + h * B, hist + (h - 1) * B, B);  // np.roll(..., 1, axis=0)
+      for (int b = 0; b < B; ++b) {
+        const double ang = angles[b] + s->heading[i];
+        const double cs = std::cos(ang), sn = std::sin(ang);
+        int hits = 0, idx = 255;
+        for (int r = 0; r < R && hits < 2; ++r) {
+          const double x = s->pos_x[i] + ranges[r] * cs, y = s->pos_y[i] + ranges[r] * sn;
+          long gr, gc;
+          bool in_map;
+          to_cell(*m, x, y, gr, gc, in_map);
+          bool hit = false;
+          if (in_map) {
+            const double dc = static_cast<double>(gc - ec), dr = static_cast<double>(gr - er);
+            const bool ego = ego_in && (dc * dc + dr * dr < err);
+            hit = grid[gr * m->cols + gc] && !ego;
+          }
+          hits += hit;
+          if (hits == 1) idx = r;  // np.where(cumsum == 1) + duplicate-index assignment keeps the LAST such sample
+        }
+        hist[b] = static_cast<uint8_t>(idx);
+      }
+      if (first)
+        for (int h = 1; h < H; ++h) std::memcpy(hist + h * B, hist, B);
+      double* out = sc->out + static_cast<size_t>(i) * H * B;
+      for (int q = 0; q < H * B; ++q) out[q] = hist[q] == 255 ? sc->max_range : ranges[hist[q]];
+    }
+  }
   return 0;
 }
 

@@ -70,6 +70,25 @@ typedef struct {
   float *actions;    /* [E,N,2] the float32 all_actions array (debug / parity of the policy stage) */
 } OrcOut;
 
+/* Static map + LaserScanSensor (Map.py:6-64, sensors/LaserScanSensor.py:24-101; env.py:494-506 wall collisions).
+ * static_map: row-major uint8 [rows*cols] (1 = occupied) or NULL (all free). */
+typedef struct {
+  const uint8_t* static_map;
+  int32_t rows, cols;
+  double cell, origin_r, origin_c;
+} OrcMap;
+typedef struct {
+  uint8_t* hist;  /* [E,N,num_to_store,num_beams] range index per beam (255 = no hit) */
+  double* out;    /* [E,N,num_to_store,num_beams] meters */
+  int32_t num_beams, num_to_store, num_ranges;
+  double min_angle, max_angle, range_res, max_range;
+} OrcScan;
+/* laserscan observation of the CURRENT state (call after reset / step); an agent with step_num == 0 takes its
+ * first measurement (all history rows filled), otherwise the history is rolled. */
+int ca_oracle_laserscan(const OrcParams* p, const OrcState* s, const OrcMap* m, const OrcScan* sc);
+/* env.step with a static map: wall collisions enter the reward / in_collision logic. */
+int ca_oracle_step_map(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions, const OrcMap* m);
+
 int ca_oracle_version(void);
 
 /* (Re)initialise the envs with mask[e]!=0 (mask NULL = all) from cases[e][a][6] =

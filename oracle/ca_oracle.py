@@ -50,6 +50,17 @@ class OrcOut(C.Structure):
     _fields_ = [("obs", _D), ("rewards", _D), ("done", _U8), ("game_over", _U8), ("actions", _F)]
 
 
+class OrcMap(C.Structure):
+    _fields_ = [("static_map", _U8), ("rows", C.c_int32), ("cols", C.c_int32), ("cell", C.c_double),
+                ("origin_r", C.c_double), ("origin_c", C.c_double)]
+
+
+class OrcScan(C.Structure):
+    _fields_ = [("hist", _U8), ("out", _D), ("num_beams", C.c_int32), ("num_to_store", C.c_int32),
+                ("num_ranges", C.c_int32), ("min_angle", C.c_double), ("max_angle", C.c_double),
+                ("range_res", C.c_double), ("max_range", C.c_double)]
+
+
 _lib = None
 
 
@@ -113,6 +124,7 @@ class Oracle(object):
         self.done = np.zeros((E, N), np.uint8)
         self.game_over = np.zeros(E, np.uint8)
         self.actions = np.zeros((E, N, 2), np.float32)
+        self.cmap = None
         self._bind()
 
     def _bind(self):
@@ -143,10 +155,32 @@ class Oracle(object):
 
     def step(self, ext_actions=None):
         e = None if ext_actions is None else np.ascontiguousarray(ext_actions, np.float64)
-        rc = lib().ca_oracle_step(C.byref(self.p), C.byref(self.cs), C.byref(self.co),
-                                  None if e is None else _ptr(e, _D))
+        if self.cmap is not None:  # env.py:494-506: wall collisions against the static map
+            rc = lib().ca_oracle_step_map(C.byref(self.p), C.byref(self.cs), C.byref(self.co),
+                                          None if e is None else _ptr(e, _D), C.byref(self.cmap))
+        else:
+            rc = lib().ca_oracle_step(C.byref(self.p), C.byref(self.cs), C.byref(self.co),
+                                      None if e is None else _ptr(e, _D))
         assert rc == 0
         return self.obs, self.rewards, self.game_over
+
+    def set_map(self, static_map=None, rows=160, cols=160, cell=0.1, num_beams=512, num_to_store=3, max_range=6.0,
+                range_res=0.1):
+        """Map(16, 16, 0.1) of env.py:389-392 + a LaserScanSensor with its hard-coded parameters
+        (LaserScanSensor.py:28-39)."""
+        self.static_map = None if static_map is None else np.ascontiguousarray(static_map, np.uint8)
+        self.cmap = OrcMap(None if self.static_map is None else _ptr(self.static_map, _U8), rows, cols, cell,
+                           (rows * cell / 2.) / cell, (cols * cell / 2.) / cell)
+        R = len(np.arange(0, max_range, range_res))
+        self.scan_hist = np.full((self.E, self.N, num_to_store, num_beams), 255, np.uint8)
+        self.scan = np.zeros((self.E, self.N, num_to_store, num_beams), np.float64)
+        self.cscan = OrcScan(_ptr(self.scan_hist, _U8), _ptr(self.scan, _D), num_beams, num_to_store, R, -math.pi / 2,
+                             math.pi / 2, range_res, max_range)
+
+    def laserscan(self):
+        rc = lib().ca_oracle_laserscan(C.byref(self.p), C.byref(self.cs), C.byref(self.cmap), C.byref(self.cscan))
+        assert rc == 0
+        return self.scan
 
     def rollout(self, table, n_steps, env_id_offset=0, case_stride=None):
         table = np.ascontiguousarray(table, np.float64)

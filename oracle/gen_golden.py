@@ -44,6 +44,8 @@ SCENARIOS = {
     "clip6_rvo": dict(cfg="Clip6", kind="fixture", n=6, cases=[0, 1], policy="RVO", max_steps=400),
     # time_to_impact ordering (util.py:23-127) with K < N-1
     "tti6_rvo": dict(cfg="Tti6", kind="fixture", n=6, cases=[2, 3], policy="RVO", max_steps=400),
+    # static map with obstacles + LaserScanSensor + wall collisions (Map.py, LaserScanSensor.py, env.py:494-506)
+    "laser4": dict(cfg="Laser4", kind="laser", max_steps=90),
     # K > N-1, mixed policies / dynamics, a head-on collision, a static agent, an externally driven learner
     "mixed5": dict(cfg="Pad5", kind="mixed", max_steps=120),
     # training-mode rules (DT=0.2, MAX_TIME_RATIO=2 -> time-outs; game over when the learner is done)
@@ -71,8 +73,14 @@ def _snapshot(agents):
 def _obs_array(obs, agents, states):
     rows = []
     for i in range(len(agents)):
-        rows.append(np.concatenate([np.asarray(obs[i][s], dtype=np.float64).reshape(-1) for s in states]))
+        rows.append(np.concatenate([np.asarray(obs[i][s], dtype=np.float64).reshape(-1) for s in states
+                                    if s != "laserscan"]))
     return np.array(rows)
+
+
+def _laser_idx(obs, agents):
+    """laserscan observation [N,3,512] as uint8 range indices (values are multiples of 0.1 m; 60 = max range 6.0)"""
+    return np.array([np.rint(np.asarray(obs[i]["laserscan"]) / 0.1).astype(np.uint8) for i in range(len(agents))])
 
 
 POLICY_IDS = {"RVO": 0, "NonCooperativePolicy": 1, "Static": 2, "External": 3, "learning": 4}
@@ -86,6 +94,9 @@ def _run_episode(env, agents, Config, ext_fn, max_steps):
     st, fl = _snapshot(env.agents)
     rec = dict(state=[st], flags=[fl], obs=[_obs_array(obs, env.agents, states)], rewards=[], done=[], game_over=[],
                ext=[])
+    laser = "laserscan" in states
+    if laser:
+        rec["laser"] = [_laser_idx(obs, env.agents)]
     for step in range(max_steps):
         actions = ext_fn(step, env.agents) if ext_fn else {}
         ext = np.zeros((len(env.agents), 2))
@@ -100,6 +111,8 @@ def _run_episode(env, agents, Config, ext_fn, max_steps):
         rec["done"].append(np.array([info["which_agents_done"][a.id] for a in env.agents], dtype=np.uint8))
         rec["game_over"].append(bool(over))
         rec["ext"].append(ext)
+        if laser:
+            rec["laser"].append(_laser_idx(obs, env.agents))
         if over:
             break
     out = {k: np.array(v) for k, v in rec.items()}
@@ -169,6 +182,35 @@ def worker(name):
             for k, v in rec.items():
                 out["c%d_%s" % (c, k)] = v
         out["cases"] = np.array(sc["cases"])
+    elif sc["kind"] == "laser":
+        from gym_collision_avoidance.envs.dynamics.UnicycleDynamics import UnicycleDynamics
+        from gym_collision_avoidance.envs.sensors.OtherAgentsStatesSensor import OtherAgentsStatesSensor
+        from gym_collision_avoidance.envs.sensors.LaserScanSensor import LaserScanSensor
+        static = np.zeros((160, 160), dtype=bool)      # row = floor(80 - y/0.1), col = floor(80 + x/0.1)
+        static[60:66, 95:125] = True                    # a wall north-east of the origin
+        static[100:130, 38:42] = True                   # a pillar to the south-west
+        static[78:83, 118:122] = True                   # a block on agent 3's straight line to its goal
+
+        class EnvWithObstacles(CollisionAvoidanceEnv):  # the reference loads maps from image files through imageio /
+            def _init_static_map(self):                 # scipy.misc.imresize (both absent here): inject the array
+                CollisionAvoidanceEnv._init_static_map(self)
+                self.map.static_map = static.copy()
+
+        env = EnvWithObstacles()
+        f = np.float64
+        S = [OtherAgentsStatesSensor, LaserScanSensor]
+
+        def mk(px, py, gx, gy, r, ps, pol, i):
+            h = np.arctan2(f(gy) - f(py), f(gx) - f(px))
+            return Agent(f(px), f(py), f(gx), f(gy), f(r), f(ps), h, tc.policy_dict[pol], UnicycleDynamics, S, i)
+
+        agents = [mk(-4.1, 0.3, 3.8, 0.9, 0.41, 1.05, "RVO", 0), mk(4.3, 1.1, -3.9, 0.2, 0.36, 0.93, "RVO", 1),
+                  mk(-2.0, -4.6, 1.1, 5.2, 0.3, 1.2, "noncoop", 2), mk(6.2, -0.1, -0.5, -0.3, 0.45, 0.8, "noncoop", 3)]
+        rec = _run_episode(env, agents, Config, None, sc["max_steps"])
+        for k, v in rec.items():
+            out["c0_%s" % k] = v
+        out["cases"] = np.array([0])
+        out["static_map"] = static
     else:
         train = name.startswith("train")
         agents = _mixed_agents(tc, Agent, train)

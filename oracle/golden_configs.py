@@ -66,3 +66,13 @@ class Train5(Config):       # training-mode rules: DT=0.2, MAX_TIME_RATIO=2, gam
         self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 5
         Config.__init__(self)
         self.STORE_HISTORY = False
+
+
+class Laser4(_Eval):        # static map + LaserScanSensor (config 5 in miniature): 'laserscan' joins the observation
+    N_MAX = 4
+
+    def __init__(self):
+        self.USE_STATIC_MAP = True
+        self.STATES_IN_OBS = ['is_learning', 'num_other_agents', 'dist_to_goal', 'heading_ego_frame', 'pref_speed',
+                              'radius', 'other_agents_states', 'laserscan']
+        _Eval.__init__(self)

@@ -20,6 +20,8 @@ class Episode(object):
         self.state, self.flags, self.obs = g("state"), g("flags"), g("obs")
         self.rewards, self.done, self.game_over, self.ext = g("rewards"), g("done"), g("game_over"), g("ext")
         self.policy, self.dynamics = g("policy"), g("dynamics")
+        self.laser = z["c%d_laser" % c] if ("c%d_laser" % c) in z else None
+        self.static_map = z["static_map"] if "static_map" in z else None
         self.T = self.rewards.shape[0]
         self.N = self.state.shape[1]
 

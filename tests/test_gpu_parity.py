@@ -285,6 +285,70 @@ def test_too_many_agents_is_a_loud_error():
         core.BatchedSim(core.make_params(2, 65)).observe()
 
 
+# ---------------------------------------------------------------- static map + LaserScanSensor (config 5 row)
+def _laser_idx(scan):
+    return np.rint(np.asarray(scan, dtype=np.float64) / 0.1).astype(np.uint8)
+
+
+def test_laserscan_golden_episode():
+    """Map rasterisation, ray-march, history roll and wall collisions against the reference-recorded episode"""
+    nat, core, orc = _mods()
+    meta, eps = gu.load("laser4")
+    ep = eps[0]
+    g = _golden_sim(meta, ep)
+    g.set_map(ep.static_map)
+    cases, head = ep.case()
+    g.reset(cases[None], headings=head[None])
+    mism = int((_laser_idx(g.laserscan().cpu().numpy()[0]) != ep.laser[0]).sum())
+    for t in range(ep.T):
+        g.step(ep.ext[t][None])
+        _check_golden_step(g, ep, t, 1e-4, 1e-3)
+        mism += int((_laser_idx(g.laserscan().cpu().numpy()[0]) != ep.laser[t + 1]).sum())
+    assert mism <= 3, mism       # a sample within 1 ulp of a cell edge may floor differently (libm cos / sin)
+    assert (g.state["flags"].cpu().numpy() & nat.IN_COLLISION).any()   # the wall collision happened here too
+
+
+@pytest.mark.parametrize("N,E,with_map", [(4, 50, True), (10, 40, True), (10, 40, False), (50, 6, True)])
+def test_laserscan_and_walls_vs_oracle(N, E, with_map):
+    """random scenes with random static obstacles, re-injected every step; scans must agree on (practically) every beam"""
+    nat, core, orc = _mods()
+    rng = np.random.default_rng(N + E)
+    o, g = _pair(E, N, min(N - 1, 9))
+    pol = np.where(rng.random((E, N)) < 0.5, orc.POL_RVO, orc.POL_NONCOOP).astype(np.int32)
+    o.s["policy"][:] = pol.reshape(-1)
+    g.set_plugins(pol)
+    static = None
+    if with_map:
+        static = rng.random((160, 160)) < 0.004
+        static[70:74, 20:140] = True
+    o.set_map(static)
+    g.set_map(static)
+    cases = np.zeros((E, N, 6))
+    cases[..., 0:2] = rng.uniform(-7, 7, (E, N, 2))
+    cases[..., 2:4] = rng.uniform(-7, 7, (E, N, 2))
+    cases[..., 4] = rng.uniform(0.5, 2.0, (E, N))
+    cases[..., 5] = rng.uniform(0.2, 0.8, (E, N))
+    cases[0, 0, 0:2] = [9.5, 9.5]      # an agent outside the 16 m x 16 m map: no disc, no ego mask, beams mostly off-map
+    o.reset(cases)
+    g.reset(cases)
+    total = bad = 0
+    for t in range(12):
+        if t:
+            _upload(o, g)
+            o.step()
+            g.step()
+            _compare(o, g, what="laser N=%d step %d" % (N, t))
+        want = _laser_idx(o.laserscan())
+        got = _laser_idx(g.laserscan().cpu().numpy())
+        assert np.array_equal(g.scan_hist.cpu().numpy() == 255, want == 60)
+        bad += int((got != want).sum())
+        total += want.size
+        o.scan_hist[:] = g.scan_hist.cpu().numpy()   # keep the histories in step despite a rare 1-ulp beam
+    assert bad <= max(3, total // 200000), "%d of %d beams differ" % (bad, total)
+    if with_map:
+        assert (o.s["flags"] & orc.IN_COLLISION).any()
+
+
 # ---------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("N,E,K", [(1, 7, 3), (2, 1, 1), (7, 130, 3), (10, 1, 9), (13, 41, 20), (33, 9, 8),
                                    (64, 3, 10), (50, 11, 49)])

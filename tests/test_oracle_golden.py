@@ -91,3 +91,30 @@ def test_round2_matches_numpy_scalar_round():
                          np.array([0.285, 0.575, 1.005, 2.675, 0.125, -0.001, 1.115, 0.0, -0.0])])
     for x in xs:
         assert orc.round2(x) == float(round(np.float64(x), 2))
+
+
+def test_laserscan_map_and_wall_collisions():
+    """Map rasterisation + LaserScanSensor ray-march + static-obstacle collisions against the reference
+    (tests/golden/laser4.npz: 4 agents, 3 obstacles, 90 steps, 'laserscan' in the observation)."""
+    meta, eps = gu.load("laser4")
+    ep = eps[0]
+    assert ep.laser.shape == (ep.T + 1, 4, 3, 512) and ep.static_map.any()
+    o = make_oracle(meta, ep)
+    o.set_map(ep.static_map)
+    cases, head = ep.case()
+    o.reset(cases[None], headings=head[None])
+    o.laserscan()
+    mism = 0
+    def cmp(t):
+        got = np.rint(o.scan[0] / 0.1).astype(np.uint8)
+        return int((got != ep.laser[t]).sum())
+    mism += cmp(0)
+    for t in range(ep.T):
+        o.step(ep.ext[t][None])
+        check_step(o, ep, t, TOL)
+        o.laserscan()
+        mism += cmp(t + 1)
+    # a beam sample that lands within 1 ulp of a cell edge may floor differently (np.cos vs libm cos)
+    assert mism <= 3, mism
+    assert (ep.flags[-1] & orc.IN_COLLISION).any(), "the scenario is meant to contain a wall collision"
+    assert ep.laser.min() < 60 and (ep.laser == 60).any()
