@@ -169,7 +169,10 @@ class Agent(object):
         row = self._obs_row()
         K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
         oa = np.zeros((K, 7)) if row is None else row[6:6 + 7 * K].astype(np.float64).reshape(K, 7)
-        return {"other_agents_states": oa}
+        data = {"other_agents_states": oa}
+        if self._env is not None and self._env._sim is not None and self._env._sim.scan is not None:
+            data["laserscan"] = self._env._scan_host()[self._e, self._a].astype(np.float64)
+        return data
 
     def get_sensor_data(self, sensor_name):
         return self.sensor_data.get(sensor_name)
@@ -190,7 +193,8 @@ class Agent(object):
                    "dist_to_goal": lambda: self.dist_to_goal, "heading_ego_frame": lambda: self.heading_ego_frame,
                    "pref_speed": lambda: self.pref_speed, "radius": lambda: self.radius,
                    "other_agent_states": lambda: self.other_agent_states,
-                   "other_agents_states": lambda: self.get_sensor_data("other_agents_states")}
+                   "other_agents_states": lambda: self.get_sensor_data("other_agents_states"),
+                   "laserscan": lambda: self.get_sensor_data("laserscan")}
         return {s: np.array(getters[s]()) for s in Config.STATES_IN_OBS}
 
     def sense(self, agents, agent_index, top_down_map):

@@ -22,6 +22,7 @@ import numpy as np
 from gym_collision_avoidance_amd import _native as nat
 from gym_collision_avoidance_amd.envs import Config
 from gym_collision_avoidance_amd.envs import test_cases as tc
+from gym_collision_avoidance_amd.envs.Map import Map
 from gym_collision_avoidance_amd.envs.policies import (ExternalPolicy, InternalPolicy, LearningPolicy,
                                                        LearningPolicyGA3C, NonCooperativePolicy, RVOPolicy,
                                                        StaticPolicy)
@@ -80,6 +81,7 @@ class CollisionAvoidanceEnv(Env):
         self._sim_key = None
         self._snap = None
         self._obs_np = None
+        self._scan_np = None
         self._fixture = None
         self._all_agents = None
 
@@ -101,8 +103,13 @@ class CollisionAvoidanceEnv(Env):
                              case_stride=self.num_envs if case_stride is None else case_stride)
         self.default_agents = None
 
-    def set_static_map(self, map_filename):
-        raise NotImplementedError("static maps / map sensors are a 'next' row (SURVEY.md section 8f)")
+    def set_static_map(self, static_map):
+        """The static obstacles used when Config.USE_STATIC_MAP: a bool array [160, 160] (True = occupied; row =
+        floor(80 - y/0.1), col = floor(80 + x/0.1), Map.py:26-32) or None for an empty map.  (The reference takes an
+        image file name here, collision_avoidance_env.py:369-376; its loader needs imageio + scipy.misc.imresize.)"""
+        if isinstance(static_map, str):
+            raise NotImplementedError("pass the occupancy grid as a bool array, not an image file name")
+        self.static_map_filename = static_map
 
     def set_plot_save_dir(self, plot_save_dir):
         self.plot_save_dir = plot_save_dir  # accepted and ignored: no plotting here
@@ -143,10 +150,13 @@ class CollisionAvoidanceEnv(Env):
         self.episode_step_number += 1
         ext = self._external_actions(actions)
         sim.step(ext)
-        self._snap, self._obs_np = None, None
+        self._snap, self._obs_np, self._scan_np = None, None, None
+        if Config.USE_STATIC_MAP:
+            sim.laserscan()
         if Config.STORE_HISTORY and self.num_envs == 1:
             self._record_history()
         if self.num_envs > 1:
+            # batched: 'laserscan' (if enabled) is the device tensor env.laserscan [E, N, 3, 512]
             info = {"which_agents_done": sim.done.bool(),
                     "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
             return sim.obs, sim.rewards, sim.game_over.bool(), False, info
@@ -272,7 +282,12 @@ class CollisionAvoidanceEnv(Env):
             if per_env is None or per_env[e] is not None or e == 0:
                 for a_idx, agent in enumerate(g):
                     agent._bind(self, e, a_idx)
-        self._snap, self._obs_np = None, None
+        self._snap, self._obs_np, self._scan_np = None, None, None
+        if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
+            self.map = Map(16, 16, 0.1, static_map=self.static_map_filename)
+            sim.set_map(self.map.static_map if self.map.static_map.any() else None, num_beams=Config.LASERSCAN_LENGTH,
+                        num_to_store=Config.LASERSCAN_NUM_PAST)
+            sim.laserscan()
         if Config.STORE_HISTORY and E == 1:
             self._record_history(initial=True)
 
@@ -316,6 +331,11 @@ class CollisionAvoidanceEnv(Env):
             self._obs_np = self._sim.obs.cpu().numpy()
         return self._obs_np
 
+    def _scan_host(self):
+        if self._scan_np is None:
+            self._scan_np = self._sim.scan.cpu().numpy()
+        return self._scan_np
+
     def _write_agent(self, e, a, **fields):
         for name, v in fields.items():
             self._sim.state[name][e, a] = float(v)
@@ -339,6 +359,8 @@ class CollisionAvoidanceEnv(Env):
             for s in Config.STATES_IN_OBS:
                 if s == "other_agents_states":
                     obs[s] = row[i, 6:6 + 7 * K].astype(np.float64).reshape(K, 7)
+                elif s == "laserscan":
+                    obs[s] = self._scan_host()[0, i].astype(np.float64)
                 elif s == "other_agent_states":
                     obs[s] = row[i, 6:13].astype(np.float64)
                 elif s == "is_learning":
@@ -377,6 +399,11 @@ class CollisionAvoidanceEnv(Env):
                                                 self.reward_wiggly_behavior])
         self.min_possible_reward = float(np.min(self.possible_reward_values))
         self.max_possible_reward = float(np.max(self.possible_reward_values))
+
+    @property
+    def laserscan(self):
+        """float32 device tensor [E, N, LASERSCAN_NUM_PAST, LASERSCAN_LENGTH] (Config.USE_STATIC_MAP only)."""
+        return None if self._sim is None else self._sim.scan
 
     # ------------------------------------------------------------------ batched extras
     def episode_stats(self):

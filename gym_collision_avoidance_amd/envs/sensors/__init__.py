@@ -1,2 +1,3 @@
 from .Sensor import Sensor
 from .OtherAgentsStatesSensor import OtherAgentsStatesSensor
+from .LaserScanSensor import LaserScanSensor

@@ -18,7 +18,7 @@ from gym_collision_avoidance_amd.envs.dynamics import (ExternalDynamics, Unicycl
 from gym_collision_avoidance_amd.envs.policies import (CARRLPolicy, ExternalPolicy, LearningPolicy,
                                                        LearningPolicyGA3C, NonCooperativePolicy, RVOPolicy,
                                                        StaticPolicy)
-from gym_collision_avoidance_amd.envs.sensors import OtherAgentsStatesSensor
+from gym_collision_avoidance_amd.envs.sensors import LaserScanSensor, OtherAgentsStatesSensor
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))), "data", "test_cases.npz")
 
@@ -31,7 +31,7 @@ policy_dict = {
     "learning_ga3c": LearningPolicyGA3C,
     "static": StaticPolicy,
 }
-sensor_dict = {"other_agents_states": OtherAgentsStatesSensor}
+sensor_dict = {"other_agents_states": OtherAgentsStatesSensor, "laserscan": LaserScanSensor}
 dynamics_dict = {"unicycle": UnicycleDynamics, "unicycle_max_turn_rate": UnicycleDynamicsMaxTurnRate,
                  "external": ExternalDynamics}
 

@@ -62,3 +62,13 @@ class Train5(Config):
         self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 5
         Config.__init__(self)
         self.STORE_HISTORY = False
+
+
+class Laser4(_Eval):
+    N_MAX = 4
+
+    def __init__(self):
+        self.USE_STATIC_MAP = True
+        self.STATES_IN_OBS = ['is_learning', 'num_other_agents', 'dist_to_goal', 'heading_ego_frame', 'pref_speed',
+                              'radius', 'other_agents_states', 'laserscan']
+        _Eval.__init__(self)

@@ -181,3 +181,33 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["episode_stats"]["episodes"] > 2 * 256 * 0.8      # both shards' episodes were summed
     assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
+
+
+def test_env_api_laserscan_episode():
+    """Config.USE_STATIC_MAP + LaserScanSensor through the reference-shaped API against the reference's record"""
+    Config, tc, Env = envtools.fresh("Laser4")
+    from gym_collision_avoidance_amd.envs.agent import Agent
+    from gym_collision_avoidance_amd.envs.sensors import LaserScanSensor, OtherAgentsStatesSensor
+    meta, eps = gu.load("laser4")
+    ep = eps[0]
+    cases, head = ep.case()
+    agents = [Agent(c[0], c[1], c[2], c[3], c[5], c[4], head[i], tc.policy_dict[POL[int(ep.policy[i])]],
+                    tc.dynamics_dict[DYN[int(ep.dynamics[i])]], [OtherAgentsStatesSensor, LaserScanSensor], i)
+              for i, c in enumerate(cases)]
+    env = Env()
+    env.set_static_map(ep.static_map)
+    env.set_agents(agents)
+    obs, _ = env.reset()
+    assert obs[0]["laserscan"].shape == (3, 512) and env.observation_space.spaces[0].spaces["laserscan"].shape == (3, 512)
+    idx = lambda o: np.array([np.rint(o[i]["laserscan"] / 0.1).astype(np.uint8) for i in range(ep.N)])
+    mism = int((idx(obs) != ep.laser[0]).sum())
+    ext_idx = [i for i, a in enumerate(agents) if a.policy.is_external]
+    for t in range(ep.T):
+        obs, rew, over, _, info = env.step({i: ep.ext[t][i] for i in ext_idx})
+        np.testing.assert_allclose(rew, ep.rewards[t], rtol=0, atol=1e-5)
+        assert [info["which_agents_done"][a.id] for a in agents] == list(ep.done[t].astype(bool))
+        mism += int((idx(obs) != ep.laser[t + 1]).sum())
+    assert mism <= 3, mism
+    assert any(a.in_collision for a in agents)      # somebody ran into the wall
+    assert np.array_equal(agents[0].get_sensor_data("laserscan"), obs[0]["laserscan"])
+    assert env.laserscan.shape == (1, ep.N, 3, 512)

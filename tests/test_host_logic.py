@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(REPO, "include", "cagpu.h")).read()
     declared = set(re.findall(r"\b(cagpu_[a-z_]+)\s*\(", hdr))
     assert {"cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_rollout", "cagpu_orca",
-            "cagpu_observe"} <= declared
+            "cagpu_observe", "cagpu_step_map", "cagpu_laserscan"} <= declared
     so = os.path.join(REPO, "gym_collision_avoidance_amd", "libcagpu.so")
     if not os.path.exists(so):
         from gym_collision_avoidance_amd import build_native
@@ -38,6 +38,30 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
     assert ctypes.sizeof(nat.CaAutoReset) == 32
     assert nat.CaParams.dt.offset == 32
+    assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
+    assert ctypes.sizeof(nat.CaScan) == 2 * 8 + 4 * 4 + 4 * 8 and nat.CaScan.min_angle.offset == 32
+
+
+def test_map_indices_and_laserscan_sensor_registration():
+    """Map.world_coordinates_to_map_indices (Map.py:26-32) and the 'laserscan' entry of sensor_dict"""
+    from tests import envtools
+    Config, tc, Env = envtools.fresh("Laser4")
+    from gym_collision_avoidance_amd.envs.Map import Map
+    m = Map(16, 16, 0.1)
+    assert m.static_map.shape == (160, 160) and not m.static_map.any()
+    (gx, gy), ok = m.world_coordinates_to_map_indices([0.0, 0.0])
+    assert (gx, gy, ok) == (80, 80, True)
+    (gx, gy), ok = m.world_coordinates_to_map_indices([-7.95, 7.95])
+    assert (gx, gy, ok) == (0, 0, True)
+    assert m.world_coordinates_to_map_indices([8.5, 0.0])[1] is False
+    s = tc.sensor_dict["laserscan"]()
+    assert (s.name, s.num_beams, s.num_to_store, s.max_range) == ("laserscan", 512, 3, 6)
+    assert Config.STATE_INFO_DICT["laserscan"]["size"] == (3, 512)
+    env = Env()
+    assert env.observation_space.spaces[0].spaces["laserscan"].shape == (3, 512)
+    with pytest.raises(NotImplementedError):
+        env.set_static_map("world_maps/002.png")
+    envtools.default()
 
 
 def test_bad_arguments_are_loud_errors_not_crashes():
