@@ -11,7 +11,7 @@ CA_OK, CA_EINVAL, CA_EUNSUPPORTED, CA_ELAUNCH, CA_ENODEVICE = 0, -1, -2, -3, -4
 AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEARNING, STILL_LEARNING = (
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
-POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C = range(6)
+POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
 OVER_ALL_DONE, OVER_AGENT0, OVER_LEARNING_DONE = range(3)
@@ -57,8 +57,16 @@ class CaScan(C.Structure):
                 ("max_angle", C.c_double), ("range_res", C.c_double), ("max_range", C.c_double)]
 
 
+NET_FIELDS = ("lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer2_kernel", "layer2_bias", "fc1_kernel",
+              "fc1_bias", "logits_kernel", "logits_bias", "input_mean", "input_std")
+
+
+class CaNet(C.Structure):
+    _fields_ = [(n, _P) for n in NET_FIELDS]
+
+
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c")
 
 _lib = None
 
@@ -87,6 +95,7 @@ def lib():
     L.cagpu_observe.argtypes = [PP, PS, PO, _P]
     L.cagpu_orca.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int32,
                              C.c_float, _P, _P]
+    L.cagpu_ga3c.argtypes = [PP, PS, _P, C.POINTER(CaNet), _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
         if n not in ("cagpu_last_error",):

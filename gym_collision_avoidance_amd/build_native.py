@@ -18,7 +18,8 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [SRC, os.path.join(HERE, "csrc", "cagpu_g16.inc"), os.path.join(HERE, "csrc", "cagpu_grouplp.inc"), os.path.join(HERE, "csrc", "cagpu_scan.inc"), os.path.join(REPO, "include", "cagpu.h")]
+    deps = [SRC, os.path.join(HERE, "csrc", "cagpu_g16.inc"), os.path.join(HERE, "csrc", "cagpu_grouplp.inc"), os.path.join(HERE, "csrc", "cagpu_scan.inc"),
+            os.path.join(HERE, "csrc", "cagpu_ga3c.inc"), os.path.join(REPO, "include", "cagpu.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -7,6 +7,7 @@ agent.py:29-138) and the per-step loops of collision_avoidance_env.py:156-234.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -44,6 +45,10 @@ def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, 
     return p
 
 
+GA3C_DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ga3c_cadrl", "IROS18",
+                                    "network_01900000.npz")
+
+
 class BatchedSim(object):
     def __init__(self, params, device="cuda:0", record_actions=False):
         if not torch.cuda.is_available():
@@ -77,6 +82,11 @@ class BatchedSim(object):
         self._map = None
         self._scan = None
         self.scan = None
+        self._net = None          # GA3C-CADRL weights (load_ga3c)
+        self._net_tensors = None
+        self._has_ga3c = False    # some agent's policy is CA_POL_GA3C_CADRL (set_plugins)
+        self._ga3c_ext = None
+        self.ga3c_logits = None
 
     # ---------------------------------------------------------------- plumbing
     def _stream(self):
@@ -104,6 +114,46 @@ class BatchedSim(object):
                (stl * nat.STILL_LEARNING)
         cur = self.state["flags"]
         cur.copy_((cur & 0x3F) | torch.as_tensor(bits.astype(np.int32), device=self.device))
+        self._has_ga3c = bool((pol == nat.POL_GA3C_CADRL).any())
+
+    def load_ga3c(self, weights=None, keep_logits=False):
+        """Upload the GA3C-CADRL network (GA3CCADRLPolicy.initialize_network, GA3CCADRLPolicy.py:23-47).  `weights`:
+        an .npz written by oracle/extract_ga3c_weights.py (default: the shipped IROS18/network_01900000, the
+        reference's default checkpoint) or a dict of float32 arrays with the same keys."""
+        if weights is None:
+            weights = GA3C_DEFAULT_WEIGHTS
+        if isinstance(weights, str):
+            with np.load(weights) as z:
+                weights = {k: z[k] for k in z.files}
+        names = {"logits_kernel": "logits_p_kernel", "logits_bias": "logits_p_bias"}
+        shapes = {"lstm_kernel": (71, 256), "lstm_bias": (256,), "layer1_kernel": (68, 256), "layer1_bias": (256,),
+                  "layer2_kernel": (256, 256), "layer2_bias": (256,), "fc1_kernel": (256, 256), "fc1_bias": (256,),
+                  "logits_kernel": (256, 11), "logits_bias": (11,), "input_mean": (138,), "input_std": (138,)}
+        ts = {}
+        for f in nat.NET_FIELDS:
+            a = np.ascontiguousarray(weights[names.get(f, f)], dtype=np.float32)
+            if a.shape != shapes[f]:
+                raise ValueError("GA3C-CADRL weight %s has shape %s, expected %s" % (f, a.shape, shapes[f]))
+            ts[f] = torch.from_numpy(a).to(self.device)
+        self._net_tensors = ts
+        self._net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS})
+        self.ga3c_logits = torch.zeros((self.E, self.N, 11), dtype=torch.float32, device=self.device) \
+            if keep_logits else None
+
+    def ga3c(self, ext=None):
+        """Query the network for every live GA3C-CADRL agent on the CURRENT observation; the action indices land in
+        `ext[..., 0]` (a float64 [E,N,2] tensor, allocated here if not given), which step() then consumes."""
+        if self._net is None:
+            raise nat.CagpuError("GA3C-CADRL agents present but no network loaded: call load_ga3c() "
+                                 "(policy.initialize_network() in the env API)")
+        if ext is None:
+            if self._ga3c_ext is None:
+                self._ga3c_ext = torch.zeros((self.E, self.N, 2), dtype=torch.float64, device=self.device)
+            ext = self._ga3c_ext
+        nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(self._net),
+                                      ext.data_ptr(), None if self.ga3c_logits is None else self.ga3c_logits.data_ptr(),
+                                      self._stream()))
+        return ext
 
     def set_fixture_table(self, table, env_id_offset=0, case_stride=None):
         """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,
@@ -172,6 +222,12 @@ class BatchedSim(object):
         e = self._dev(ext_actions, torch.float64)
         if e is not None:
             assert tuple(e.shape) == (self.E, self.N, 2), e.shape
+        if self._has_ga3c:  # policy query on the pre-step observation (collision_avoidance_env.py:319-323)
+            if e is not None:  # the caller's external actions travel in the same buffer; never write into theirs
+                if self._ga3c_ext is None:
+                    self._ga3c_ext = torch.zeros((self.E, self.N, 2), dtype=torch.float64, device=self.device)
+                self._ga3c_ext.copy_(e)
+            e = self.ga3c(None if e is None else self._ga3c_ext)
         if self._map is not None:
             nat.check(self.lib.cagpu_step_map(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
                                               None if e is None else e.data_ptr(),
@@ -185,6 +241,10 @@ class BatchedSim(object):
         return self.obs, self.rewards, self.game_over
 
     def rollout(self, n_steps, ext_actions=None):
+        if self._has_ga3c:  # the network runs between steps: one inference + one step launch per step
+            for _ in range(int(n_steps)):
+                self.step(ext_actions)
+            return self.obs, self.rewards, self.game_over
         e = self._dev(ext_actions, torch.float64)
         nat.check(self.lib.cagpu_rollout(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
                                          None if e is None else e.data_ptr(),

@@ -343,6 +343,7 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
 #include "cagpu_scan.inc"
+#include "cagpu_ga3c.inc"
 
 // fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
 __host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 10 * 4 + 4 * 4); }
@@ -643,7 +644,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             } else if (pol == CA_POL_LEARNING) {  // LearningPolicy.py:29-33
               dh = p.max_heading_change * (2. * e1 - 1.);
               spd = r.ps * e0;
-            } else if (pol == CA_POL_LEARNING_GA3C) {  // LearningPolicyGA3C.py:24-26, network.py:7-16
+            } else if (pol == CA_POL_LEARNING_GA3C || pol == CA_POL_GA3C_CADRL) {  // LearningPolicyGA3C.py:24-26,
+              // GA3CCADRLPolicy.py:81-84 (index from cagpu_ga3c), network.py:7-16
               int q = static_cast<int>(e0);
               q = q < 0 ? 0 : (q > 10 ? 10 : q);
               const int hq = (q < 5) ? q - 2 : ((q - 5) % 3 - 1) * 2;  // heading index in units of pi/12
@@ -1255,6 +1257,33 @@ int cagpu_laserscan(const CaParams* p, const CaState* s, const CaMap* map, const
   hipLaunchKernelGGL(scan_kernel, dim3(static_cast<unsigned>(p->num_envs)), dim3(SCAN_NT), total,
                      static_cast<hipStream_t>(stream), k);
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
+}
+
+int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNet* net, double* ext_actions, float* logits,
+               void* stream) {
+  if (!p || !s || !obs || !net || !ext_actions) return fail(CA_EINVAL, "cagpu_ga3c: NULL argument%s");
+  if (p->num_envs < 1 || p->num_agents < 1 || p->max_obs < 0) return fail(CA_EINVAL, "cagpu_ga3c: bad sizes%s");
+  if (!s->flags) return fail(CA_EINVAL, "cagpu_ga3c: NULL state pointer%s");
+  const void* w[] = {net->lstm_kernel, net->lstm_bias, net->layer1_kernel, net->layer1_bias, net->layer2_kernel,
+                     net->layer2_bias, net->fc1_kernel, net->fc1_bias, net->logits_kernel, net->logits_bias,
+                     net->input_mean, net->input_std};
+  for (const void* q : w)
+    if (!q || (reinterpret_cast<uintptr_t>(q) & 15)) return fail(CA_EINVAL, "cagpu_ga3c: NULL or not 16-byte aligned weight pointer%s");
+  ga3c::Args k;
+  std::memset(&k, 0, sizeof(k));
+  k.obs = obs; k.flags = s->flags;
+  k.B = static_cast<long>(p->num_envs) * p->num_agents;
+  k.W = 6 + 7 * p->max_obs;
+  k.net = *net; k.ext = ext_actions; k.logits = logits;
+  static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ga3c::ga3c_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ga3c::LDS_BYTES));
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const unsigned grid = static_cast<unsigned>((k.B + ga3c::TM - 1) / ga3c::TM);
+  hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), ga3c::LDS_BYTES, static_cast<hipStream_t>(stream), k);
+  e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }

@@ -23,12 +23,13 @@ from gym_collision_avoidance_amd import _native as nat
 from gym_collision_avoidance_amd.envs import Config
 from gym_collision_avoidance_amd.envs import test_cases as tc
 from gym_collision_avoidance_amd.envs.Map import Map
-from gym_collision_avoidance_amd.envs.policies import (ExternalPolicy, InternalPolicy, LearningPolicy,
+from gym_collision_avoidance_amd.envs.policies import (ExternalPolicy, GA3CCADRLPolicy, InternalPolicy, LearningPolicy,
                                                        LearningPolicyGA3C, NonCooperativePolicy, RVOPolicy,
                                                        StaticPolicy)
 from gym_collision_avoidance_amd.envs.spaces import Box, Dict, Env
 
-_BUILTIN_POLICIES = (RVOPolicy, NonCooperativePolicy, StaticPolicy, ExternalPolicy, LearningPolicy, LearningPolicyGA3C)
+_BUILTIN_POLICIES = (RVOPolicy, NonCooperativePolicy, StaticPolicy, ExternalPolicy, LearningPolicy, LearningPolicyGA3C,
+                     GA3CCADRLPolicy)
 _SORT = {"closest_first": nat.SORT_CLOSEST_FIRST, "closest_last": nat.SORT_CLOSEST_LAST,
          "time_to_impact": nat.SORT_TIME_TO_IMPACT}
 _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed", "time_remaining",
@@ -278,6 +279,16 @@ class CollisionAvoidanceEnv(Env):
             sim.reset(cases, headings=heads)
         if self._host_policies and E > 1:
             raise NotImplementedError("user-defined Python policies are a single-env convenience path")
+        nets = [a.policy for g in groups for a in g if isinstance(a.policy, GA3CCADRLPolicy)]
+        if nets:  # GA3CCADRLPolicy.initialize_network must have run (the reference has no session otherwise)
+            paths = {n.weights_path for n in nets}
+            if None in paths:
+                raise RuntimeError("a GA3CCADRLPolicy agent was not initialised: call agent.policy.initialize_network()")
+            if len(paths) > 1:
+                raise NotImplementedError("all GA3C-CADRL agents of a batch must share one checkpoint: %s" % sorted(paths))
+            if getattr(sim, "_net_path", None) != nets[0].weights_path:
+                sim.load_ga3c(nets[0].weights)
+                sim._net_path = nets[0].weights_path
         for e, g in enumerate(groups if self._fixture is None else [agents0]):
             if per_env is None or per_env[e] is not None or e == 0:
                 for a_idx, agent in enumerate(g):

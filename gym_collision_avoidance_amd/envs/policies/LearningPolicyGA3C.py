@@ -4,14 +4,7 @@ from gym_collision_avoidance_amd import _native as nat
 from .LearningPolicy import LearningPolicy
 
 
-class Actions(object):
-    """The 11 discrete GA3C-CADRL actions (reference policies/GA3C_CADRL/network.py:7-16): [speed factor, dheading]."""
-
-    def __init__(self):
-        s6, s12 = np.pi / 6, np.pi / 12
-        self.actions = np.array([[1, -s6], [1, -s12], [1, 0], [1, s12], [1, s6], [0.5, -s6], [0.5, 0], [0.5, s6],
-                                 [0, -s6], [0, 0], [0, s6]], dtype=np.float64)
-        self.num_actions = len(self.actions)
+from .GA3C_CADRL.network import Actions
 
 
 class LearningPolicyGA3C(LearningPolicy):

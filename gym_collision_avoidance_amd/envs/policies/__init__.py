@@ -11,3 +11,4 @@ from .LearningPolicy import LearningPolicy
 from .LearningPolicyGA3C import LearningPolicyGA3C
 from .RVOPolicy import RVOPolicy
 from .CARRLPolicy import CARRLPolicy
+from .GA3CCADRLPolicy import GA3CCADRLPolicy

@@ -15,7 +15,7 @@ from gym_collision_avoidance_amd.envs import Config
 from gym_collision_avoidance_amd.envs.agent import Agent
 from gym_collision_avoidance_amd.envs.dynamics import (ExternalDynamics, UnicycleDynamics,
                                                        UnicycleDynamicsMaxTurnRate)
-from gym_collision_avoidance_amd.envs.policies import (CARRLPolicy, ExternalPolicy, LearningPolicy,
+from gym_collision_avoidance_amd.envs.policies import (CARRLPolicy, ExternalPolicy, GA3CCADRLPolicy, LearningPolicy,
                                                        LearningPolicyGA3C, NonCooperativePolicy, RVOPolicy,
                                                        StaticPolicy)
 from gym_collision_avoidance_amd.envs.sensors import LaserScanSensor, OtherAgentsStatesSensor
@@ -24,6 +24,7 @@ _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))
 
 policy_dict = {
     "RVO": RVOPolicy,
+    "GA3C_CADRL": GA3CCADRLPolicy,
     "noncoop": NonCooperativePolicy,
     "carrl": CARRLPolicy,
     "external": ExternalPolicy,
@@ -120,9 +121,8 @@ def full_test_suite(num_agents, test_case_index, policies="RVO", agents_dynamics
                                      agents_sensors=agents_sensors, prev_agents=prev_agents)
 
 
-def get_testcase_two_agents(policies=("learning", "RVO")):
-    """Two agents swapping corners (test_cases.py:144-175; the reference's second default, GA3C_CADRL, is a
-    "next" row -- RVO stands in)."""
+def get_testcase_two_agents(policies=("learning", "GA3C_CADRL")):
+    """Two agents swapping corners (test_cases.py:144-175)."""
     g = 3
     return [Agent(-g, -g, g, g, 0.5, 1.0, 0.0, policy_dict[policies[0]], UnicycleDynamics,
                   [OtherAgentsStatesSensor], 0),

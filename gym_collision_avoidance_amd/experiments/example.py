@@ -29,6 +29,26 @@ def main(num_steps=200, verbose=True):
     return bool(terminated), [a.is_at_goal for a in env.agents]
 
 
+def main_two_agents(num_steps=100, verbose=True):
+    """The reference's own example (experiments/src/example.py:12-66): agent 0 runs an external (learning) policy fed
+    the constant action [1.0, 0.5], agent 1 runs the pre-trained GA3C-CADRL network."""
+    env = CollisionAvoidanceEnv()
+    agents = tc.get_testcase_two_agents()
+    [agent.policy.initialize_network() for agent in agents if hasattr(agent.policy, "initialize_network")]
+    env.set_agents(agents)
+    env.reset()
+    terminated = False
+    for i in range(num_steps):
+        actions = {0: np.array([1.0, 0.5])}
+        obs, rewards, terminated, truncated, which_agents_done = env.step(actions)
+        if terminated:
+            if verbose:
+                print("All agents finished!")
+            break
+    return bool(terminated), [a.is_at_goal for a in env.agents], [a.in_collision for a in env.agents]
+
+
 if __name__ == "__main__":
     main()
+    main_two_agents()
     print("Experiment over.")

@@ -57,7 +57,8 @@ enum {
   CA_POL_STATIC = 2,        /* policies/StaticPolicy.py                      */
   CA_POL_EXTERNAL = 3,      /* policies/ExternalPolicy.py: raw [speed, dheading] from ext_actions */
   CA_POL_LEARNING = 4,      /* policies/LearningPolicy.py: scaled ext_actions */
-  CA_POL_LEARNING_GA3C = 5  /* policies/LearningPolicyGA3C.py: discrete index in ext_actions[.,0] */
+  CA_POL_LEARNING_GA3C = 5, /* policies/LearningPolicyGA3C.py: discrete index in ext_actions[.,0] */
+  CA_POL_GA3C_CADRL = 6     /* policies/GA3CCADRLPolicy.py: discrete index written into ext_actions[.,0] by cagpu_ga3c */
 };
 /* dynamics plugin ids (test_cases.py:93-96 `dynamics_dict`) */
 enum {
@@ -148,6 +149,17 @@ typedef struct CaScan {
   double min_angle, max_angle, range_res, max_range;
 } CaScan;
 
+/* GA3C-CADRL network weights (policies/GA3C_CADRL/checkpoints/<run>/network_*.data-00000-of-00001): device float
+ * pointers in the checkpoint's own layout, kernels row-major [in, out].  LSTM gate order i, j, f, o. */
+typedef struct CaNet {
+  const float *lstm_kernel, *lstm_bias;     /* rnn/lstm_cell/{kernel [71,256], bias [256]}: input = [x_t (7), h (64)] */
+  const float *layer1_kernel, *layer1_bias; /* layer1/{kernel [68,256], bias}: input = [host (4), h_final (64)]       */
+  const float *layer2_kernel, *layer2_bias; /* layer2/{kernel [256,256], bias}                                        */
+  const float *fc1_kernel, *fc1_bias;       /* fullyconnected1/{kernel [256,256], bias}                               */
+  const float *logits_kernel, *logits_bias; /* logits_p/{kernel [256,11], bias [11]}                                  */
+  const float *input_mean, *input_std;      /* graph constants `Const`, `Const_1` [138] (= config.py:93-149)          */
+} CaNet;
+
 int cagpu_version(void);
 const char *cagpu_last_error(void);
 
@@ -180,6 +192,18 @@ int cagpu_step_map(const CaParams *p, const CaState *s, const CaOut *o, const do
  * `cumsum == 1` indexing, LaserScanSensor.py:77-81).  An agent with step_num == 0 takes its first measurement (all
  * history rows filled, :84-85), otherwise the history is rolled (:86-88). */
 int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const CaScan *scan, void *stream);
+
+/* Replaces: GA3CCADRLPolicy.find_next_action (policies/GA3CCADRLPolicy.py:49-84) + NetworkVPCore.predict_p
+ * (GA3C_CADRL/network.py:24-41, the TF1 graph of the checkpoint) for every agent whose policy is CA_POL_GA3C_CADRL and
+ * that is not done: the policy vector X[138] = obs[1:] (zero-padded / cropped), (X - mean) / std, a 64-unit LSTM over
+ * the first num_other_agents of the 19 other-agent slots, three 256-wide ReLU layers, logits_p; the argmax (index into
+ * network.Actions, network.py:7-16) goes to ext_actions[e,n,0] (and 0 to [e,n,1]), where cagpu_step turns it into
+ * [pref_speed * a0, a1] exactly as for CA_POL_LEARNING_GA3C.  obs: device float [E,N,6+7*max_obs], the observation of
+ * the CURRENT state (what the reference hands to the policy, collision_avoidance_env.py:319-323).  logits (nullable):
+ * device float [E,N,11], written for the same agents.  fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 like the
+ * TF graph. */
+int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNet *net, double *ext_actions,
+               float *logits, void *stream);
 
 /* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
  * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is

@@ -299,6 +299,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
       case ORC_POL_LEARNING:  // policies/LearningPolicy.py:29-33
         if (ext) { dh = p.max_heading_change * (2. * ext[2 * i + 1] - 1.); spd = s.pref_speed[i] * ext[2 * i]; }
         break;
+      case ORC_POL_GA3C_CADRL:  // policies/GA3CCADRLPolicy.py:81-84 (the network itself: oracle/ga3c_ref.py)
       case ORC_POL_LEARNING_GA3C: {  // policies/LearningPolicyGA3C.py:24-26 + GA3C_CADRL/network.py:7-16
         static const double tab[11][2] = {{1, -kPi / 6}, {1, -kPi / 12}, {1, 0}, {1, kPi / 12}, {1, kPi / 6}, {0.5, -kPi / 6},
                                           {0.5, 0},      {0.5, kPi / 6}, {0, -kPi / 6}, {0, 0}, {0, kPi / 6}};

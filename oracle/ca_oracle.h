@@ -31,7 +31,8 @@ enum {
   ORC_STILL_LEARNING = 1u << 7    /* policy.is_still_learning       (Policy.py:13)     */
 };
 /* policy ids (test_cases.py:68-85 registry) */
-enum { ORC_POL_RVO = 0, ORC_POL_NONCOOP = 1, ORC_POL_STATIC = 2, ORC_POL_EXTERNAL = 3, ORC_POL_LEARNING = 4, ORC_POL_LEARNING_GA3C = 5 };
+enum { ORC_POL_RVO = 0, ORC_POL_NONCOOP = 1, ORC_POL_STATIC = 2, ORC_POL_EXTERNAL = 3, ORC_POL_LEARNING = 4, ORC_POL_LEARNING_GA3C = 5,
+       ORC_POL_GA3C_CADRL = 6 /* index computed by oracle/ga3c_ref.py, handed in through ext like LEARNING_GA3C */ };
 /* dynamics ids (test_cases.py:93-96 + UnicycleDynamicsMaxTurnRate.py) */
 enum { ORC_DYN_UNICYCLE = 0, ORC_DYN_MAX_TURN_RATE = 1, ORC_DYN_EXTERNAL = 2 };
 /* agent_sorting_method (OtherAgentsStatesSensor.py:34-52) */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "_build", "libca_oracle.so")
 # flag bits / ids: mirror oracle/ca_oracle.h
 AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEARNING, STILL_LEARNING = (
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
-POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C = range(6)
+POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
 OVER_ALL_DONE, OVER_AGENT0, OVER_LEARNING_DONE = range(3)
@@ -125,6 +125,8 @@ class Oracle(object):
         self.game_over = np.zeros(E, np.uint8)
         self.actions = np.zeros((E, N, 2), np.float32)
         self.cmap = None
+        self.net = None           # oracle/ga3c_ref.GA3CNet, created on first use
+        self.ga3c_index = None    # [E*N] last action indices chosen by the network (-1 = not queried)
         self._bind()
 
     def _bind(self):
@@ -153,7 +155,26 @@ class Oracle(object):
         assert rc == 0
         return self.obs
 
+    def ga3c_query(self, ext_actions=None):
+        """GA3CCADRLPolicy.find_next_action for every live GA3C-CADRL agent on the current observation (float32, like
+        the TF feed): the action index goes into ext[..., 0] (consumed by the C++ step like LEARNING_GA3C)."""
+        from .ga3c_ref import GA3CNet
+        if self.net is None:
+            self.net = GA3CNet()
+        e = np.zeros((self.E, self.N, 2), np.float64) if ext_actions is None else \
+            np.array(ext_actions, dtype=np.float64).reshape(self.E, self.N, 2)
+        live = (self.s["policy"] == POL_GA3C_CADRL) & ((self.s["flags"] & DONE) == 0)
+        self.ga3c_index = np.full(self.E * self.N, -1, np.int64)
+        if live.any():
+            rows = self.obs.reshape(-1, self.W)[live].astype(np.float32)
+            self.ga3c_index[live] = self.net.action_index(rows)
+            e.reshape(-1, 2)[live, 0] = self.ga3c_index[live]
+            e.reshape(-1, 2)[live, 1] = 0.0
+        return e
+
     def step(self, ext_actions=None):
+        if (self.s["policy"] == POL_GA3C_CADRL).any():
+            ext_actions = self.ga3c_query(ext_actions)
         e = None if ext_actions is None else np.ascontiguousarray(ext_actions, np.float64)
         if self.cmap is not None:  # env.py:494-506: wall collisions against the static map
             rc = lib().ca_oracle_step_map(C.byref(self.p), C.byref(self.cs), C.byref(self.co),

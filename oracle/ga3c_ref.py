@@ -1,0 +1,83 @@
+"""CPU restatement of the GA3C-CADRL policy network (test infrastructure: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline may import this).
+
+Follows the TF1 graph stored in the reference's checkpoint
+(gym_collision_avoidance/envs/policies/GA3C_CADRL/checkpoints/IROS18/network_01900000.meta, decoded by
+oracle/extract_ga3c_weights.py -- node names in the comments) and the policy wrapper
+gym_collision_avoidance/envs/policies/GA3CCADRLPolicy.py:49-84 + GA3C_CADRL/network.py:7-41.
+
+PARITY UNPINNED for this file: TensorFlow is not installed here, so the reference network cannot be executed; the
+restatement is checked only against the three known-answer cases recorded in SURVEY.md Appendix C and by behaviour
+(agents driven by it reach their goals).  float32 throughout, like the TF graph; summation order is numpy's.
+"""
+import os
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gym_collision_avoidance_amd", "data",
+                     "ga3c_cadrl", "IROS18", "network_01900000.npz")
+NUM_OTHERS, INPUT_LEN, HIDDEN = 19, 138, 64
+
+# network.Actions (network.py:7-16): [speed fraction, heading change]
+ACTIONS = np.array([[1.0, -np.pi / 6], [1.0, -np.pi / 12], [1.0, 0.0], [1.0, np.pi / 12], [1.0, np.pi / 6],
+                    [0.5, -np.pi / 6], [0.5, 0.0], [0.5, np.pi / 6],
+                    [0.0, -np.pi / 6], [0.0, 0.0], [0.0, np.pi / 6]])
+
+
+def _sigmoid(x):
+    return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
+
+
+class GA3CNet(object):
+    def __init__(self, path=_DATA):
+        with np.load(path) as z:
+            self.w = {k: z[k].astype(np.float32) for k in z.files}
+
+    def policy_vector(self, obs_rows):
+        """float32 observation rows [B, 6+7K] (is_learning, num_other_agents, dist_to_goal, heading_ego_frame,
+        pref_speed, radius, K x 7) -> the network input X [B,138]: STATES_IN_OBS minus 'is_learning', flattened
+        (GA3CCADRLPolicy.py:69-75), zero-padded / cropped to the placeholder's width (network.py:24-35)."""
+        v = np.asarray(obs_rows, dtype=np.float32)[:, 1:]
+        x = np.zeros((v.shape[0], INPUT_LEN), dtype=np.float32)
+        n = min(INPUT_LEN, v.shape[1])
+        x[:, :n] = v[:, :n]
+        return x
+
+    def logits(self, x):
+        """X [B,138] float32 -> logits_p/BiasAdd [B,11]"""
+        w = self.w
+        x = np.asarray(x, dtype=np.float32)
+        B = x.shape[0]
+        seq = x[:, 0].astype(np.int32)                          # strided_slice -> ToInt32 -> sequence_length (raw X)
+        xn = ((x - w["input_mean"]) / w["input_std"]).astype(np.float32)          # sub, div
+        host = xn[:, 1:5]                                       # strided_slice_1
+        others = xn[:, 5:].reshape(B, NUM_OTHERS, 7)            # strided_slice_2, Reshape
+        h = np.zeros((B, HIDDEN), np.float32)
+        c = np.zeros((B, HIDDEN), np.float32)
+        for t in range(NUM_OTHERS):                             # rnn/while: max_time steps, state frozen past seq
+            z = np.concatenate([others[:, t], h], axis=1) @ w["lstm_kernel"] + w["lstm_bias"]
+            i, j, f, o = np.split(z.astype(np.float32), 4, axis=1)
+            c_new = _sigmoid(f + np.float32(1.0)) * c + _sigmoid(i) * np.tanh(j)  # forget_bias 1.0
+            h_new = _sigmoid(o) * np.tanh(c_new)
+            live = (t < seq)[:, None]                           # GreaterEqual / Select_1 / Select_2
+            c = np.where(live, c_new, c).astype(np.float32)
+            h = np.where(live, h_new, h).astype(np.float32)
+        a = np.concatenate([host, h], axis=1)                   # layer1_input
+        a = np.maximum(a @ w["layer1_kernel"] + w["layer1_bias"], 0).astype(np.float32)
+        a = np.maximum(a @ w["layer2_kernel"] + w["layer2_bias"], 0).astype(np.float32)
+        a = np.maximum(a @ w["fc1_kernel"] + w["fc1_bias"], 0).astype(np.float32)
+        return (a @ w["logits_p_kernel"] + w["logits_p_bias"]).astype(np.float32)
+
+    def predict_p(self, x):
+        l = self.logits(x)
+        e = np.exp(l - l.max(axis=1, keepdims=True))
+        return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)              # Softmax
+
+    def action_index(self, obs_rows):
+        """argmax of the softmax (GA3CCADRLPolicy.py:81-82)"""
+        return np.argmax(self.predict_p(self.policy_vector(obs_rows)), axis=1)
+
+    def find_next_action(self, obs_rows, pref_speed):
+        """-> [B,2] = [pref_speed * a0, a1] (GA3CCADRLPolicy.py:83-84)"""
+        raw = ACTIONS[self.action_index(obs_rows)]
+        return np.stack([np.asarray(pref_speed, dtype=np.float64) * raw[:, 0], raw[:, 1]], axis=1)

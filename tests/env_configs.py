@@ -72,3 +72,7 @@ class Laser4(_Eval):
         self.STATES_IN_OBS = ['is_learning', 'num_other_agents', 'dist_to_goal', 'heading_ego_frame', 'pref_speed',
                               'radius', 'other_agents_states', 'laserscan']
         _Eval.__init__(self)
+
+
+class Example(_Eval):          # the reference's Example(EvaluateConfig): up to 19 agents, 18 observed
+    N_MAX = 19

@@ -211,3 +211,27 @@ def test_env_api_laserscan_episode():
     assert any(a.in_collision for a in agents)      # somebody ran into the wall
     assert np.array_equal(agents[0].get_sensor_data("laserscan"), obs[0]["laserscan"])
     assert env.laserscan.shape == (1, ep.N, 3, 512)
+
+
+def test_example_two_agents_ga3c_cadrl():
+    """the reference's own example.py: agent 0 external (constant action), agent 1 the pre-trained GA3C-CADRL net"""
+    envtools.fresh("Example")
+    import importlib
+    example = importlib.import_module("gym_collision_avoidance_amd.experiments.example")
+    terminated, at_goal, collided = example.main_two_agents(num_steps=120, verbose=False)
+    assert at_goal[1] and not any(collided)
+
+
+def test_ga3c_policy_requires_initialize_network_and_reads_tf_checkpoints(tmp_path):
+    Config, tc, Env = envtools.fresh("Example")
+    agents = tc.get_testcase_two_agents()
+    env = Env()
+    env.set_agents(agents)
+    with pytest.raises(RuntimeError):
+        env.reset()                       # initialize_network() not called (the reference has no session then)
+    with pytest.raises(FileNotFoundError):
+        agents[1].policy.initialize_network(checkpt_dir=str(tmp_path), checkpt_name="nope")
+    agents[1].policy.initialize_network(checkpt_dir="run-20190727_015942-jzuhlntn", checkpt_name="network_01490000")
+    obs, _ = env.reset()
+    obs, rew, over, _, info = env.step({0: np.array([1.0, 0.5])})
+    assert agents[1].speed_global_frame > 0.0

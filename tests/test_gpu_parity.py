@@ -441,3 +441,141 @@ def test_full_size_properties():
     st = g.episode_stats().cpu().numpy()
     assert st[0] > 0 and st[0] == st[1] + st[2] + st[3]
     assert np.isfinite(g.state["pos_x"].cpu().numpy()).all()
+
+
+# ---------------------------------------------------------------- GA3C-CADRL network (config 3 row; fp32 matrix cores)
+def _ga3c_obs(rng, E, N, K):
+    """plausible observation rows: num_other in [0, K], the first num_other slots filled, the rest zero"""
+    obs = np.zeros((E, N, 6 + 7 * K), np.float32)
+    num = rng.integers(0, K + 1, size=(E, N))
+    obs[..., 1] = num
+    obs[..., 2] = rng.uniform(0.1, 12.0, (E, N))
+    obs[..., 3] = rng.uniform(-np.pi, np.pi, (E, N))
+    obs[..., 4] = rng.uniform(0.5, 1.5, (E, N))
+    obs[..., 5] = rng.uniform(0.2, 0.8, (E, N))
+    oth = np.stack([rng.uniform(-8, 8, (E, N, K)), rng.uniform(-8, 8, (E, N, K)), rng.uniform(-1.5, 1.5, (E, N, K)),
+                    rng.uniform(-1.5, 1.5, (E, N, K)), rng.uniform(0.2, 0.8, (E, N, K)), rng.uniform(0.4, 1.6, (E, N, K)),
+                    rng.uniform(0.0, 10.0, (E, N, K))], axis=-1).astype(np.float32)
+    oth *= (np.arange(K)[None, None, :] < num[..., None])[..., None]
+    obs[..., 6:] = oth.reshape(E, N, 7 * K)
+    return obs
+
+
+@pytest.mark.parametrize("E,N,K", [(37, 5, 19), (3, 20, 19), (64, 4, 3), (9, 7, 25), (1, 1, 0)])
+def test_ga3c_logits_and_actions_vs_numpy_network(E, N, K):
+    """cagpu_ga3c against the numpy restatement of the TF graph on random observation rows: logits within fp32
+    round-off, the same argmax wherever the two best logits are not within round-off of each other; agents that are
+    done or run another policy are left alone"""
+    nat, core, orc = _mods()
+    from oracle.ga3c_ref import GA3CNet
+    rng = np.random.default_rng(E * 1000 + N * 10 + K)
+    g = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=1))
+    pol = np.full((E, N), nat.POL_GA3C_CADRL)
+    other = rng.random((E, N)) < 0.15
+    pol[other] = nat.POL_RVO
+    g.set_plugins(pol)
+    done = (rng.random((E, N)) < 0.15) & ~other
+    g.state["flags"] |= torch.from_numpy(np.where(done, nat.DONE, 0).astype(np.int32)).to(g.device)
+    obs = _ga3c_obs(rng, E, N, K)
+    g.obs.copy_(torch.from_numpy(obs))
+    g.load_ga3c(keep_logits=True)
+    g.ga3c_logits.fill_(-777.0)
+    ext = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
+    g.ga3c(ext)
+    torch.cuda.synchronize()
+    live = ~other & ~done
+    net = GA3CNet()
+    want = net.logits(net.policy_vector(obs.reshape(E * N, -1))).reshape(E, N, 11)
+    got = g.ga3c_logits.cpu().numpy()
+    ex = ext.cpu().numpy()
+    assert np.all(got[~live] == -777.0) and np.all(ex[~live] == -7.0)
+    if live.any():
+        np.testing.assert_allclose(got[live], want[live], rtol=1e-4, atol=2e-4)
+        srt = np.sort(want[live], axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-3
+        assert clear.mean() > 0.9
+        assert np.array_equal(ex[live][clear, 0], np.argmax(want[live], axis=1)[clear])
+        assert np.all(ex[live][:, 1] == 0.0) and np.all((ex[live][:, 0] >= 0) & (ex[live][:, 0] <= 10))
+        assert np.array_equal(ex[live][:, 0], np.argmax(got[live], axis=1))      # first maximum, like np.argmax
+
+
+def test_ga3c_needs_loaded_network():
+    nat, core, orc = _mods()
+    g = core.BatchedSim(core.make_params(2, 3, max_obs=19))
+    g.set_plugins(nat.POL_GA3C_CADRL)
+    with pytest.raises(nat.CagpuError):
+        g.step()
+
+
+@pytest.mark.parametrize("N,mixed", [(6, False), (10, True)])
+def test_ga3c_step_vs_oracle_reinjected(N, mixed):
+    """GA3C-CADRL agents stepping: every step starts from the oracle's state AND observation, the network's choice is
+    compared agent by agent (ties within round-off excepted) and the resulting states wherever the choices agree"""
+    nat, core, orc = _mods()
+    from gym_collision_avoidance_amd.envs import test_cases as tc
+    E, T = 48, 40
+    table = tc.fixture_table(N).astype(np.float32).astype(np.float64)
+    o, g = _pair(E, N, K=19, sort_mode=1)
+    pol = np.full((E, N), orc.POL_GA3C_CADRL)
+    if mixed:
+        pol[:, 1::3] = orc.POL_RVO
+        pol[:, 2::5] = orc.POL_NONCOOP
+    o.set_policies(pol)
+    g.set_plugins(pol)
+    g.load_ga3c(keep_logits=True)
+    o.reset(table[:E])
+    agree_total, n_total = 0, 0
+    for t in range(T):
+        _upload(o, g)
+        g.obs.copy_(torch.from_numpy(o.obs.astype(np.float32)))
+        o.step()
+        g.step()
+        torch.cuda.synchronize()
+        q = o.ga3c_index.reshape(E, N)
+        asked = q >= 0
+        gi = g._ga3c_ext.cpu().numpy()[..., 0]
+        same = (gi == q) | ~asked
+        lg = np.sort(g.ga3c_logits.cpu().numpy(), axis=-1)
+        assert np.all((lg[..., -1] - lg[..., -2])[~same] < 1e-3), "step %d: a clear-cut choice differs" % t
+        agree_total += int((same & asked).sum())
+        n_total += int(asked.sum())
+        ok = same.all(axis=1)
+        for n in ("pos_x", "pos_y", "heading", "vel_x", "vel_y"):
+            np.testing.assert_allclose(g.state[n].cpu().numpy()[ok], o.view(n)[ok], rtol=0, atol=TOL, err_msg="%s @%d" % (n, t))
+        gf = g.state["flags"].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(gf[ok] & MASK, o.view("flags")[ok] & MASK)
+        np.testing.assert_allclose(g.obs.cpu().numpy()[ok], o.obs[ok], rtol=0, atol=TOL)
+    assert n_total > 1000 and agree_total >= 0.995 * n_total, (agree_total, n_total)
+
+
+def test_ga3c_full_size_config3():
+    """BASELINE config 3 geometry: 4096 envs x 20 GA3C-CADRL agents (K = 19, closest_last): a circle swap with
+    per-env jitter; every choice is a valid action, most agents make progress, repeated runs are deterministic"""
+    nat, core, orc = _mods()
+    from gym_collision_avoidance_amd.envs import test_cases as tc
+    E, N = 4096, 20
+    rng = np.random.default_rng(3)
+    base = tc.gen_circle_test_case(N, 10.0)
+    cases = np.repeat(base[None], E, axis=0)
+    cases[..., :4] += rng.uniform(-0.4, 0.4, (E, N, 4))
+    cases[..., 4] = rng.uniform(0.6, 1.4, (E, N))
+    cases[..., 5] = rng.uniform(0.2, 0.5, (E, N))
+
+    def run():
+        g = core.BatchedSim(core.make_params(E, N, max_obs=19, sort_mode=1))
+        g.set_plugins(nat.POL_GA3C_CADRL)
+        g.load_ga3c()
+        g.reset(cases)
+        for _ in range(30):
+            g.step()
+        torch.cuda.synchronize()
+        return g
+    a, b = run(), run()
+    idx = a._ga3c_ext.cpu().numpy()[..., 0]
+    assert np.all((idx >= 0) & (idx <= 10) & (idx == np.round(idx)))
+    for n in ("pos_x", "pos_y", "heading"):
+        assert torch.equal(a.state[n], b.state[n])
+    d0 = np.hypot(cases[..., 0] - cases[..., 2], cases[..., 1] - cases[..., 3])
+    d1 = np.hypot(a.state["pos_x"].cpu().numpy() - cases[..., 2], a.state["pos_y"].cpu().numpy() - cases[..., 3])
+    assert (d1 < d0 - 1.0).mean() > 0.9
+    assert np.isfinite(a.obs.cpu().numpy()).all()

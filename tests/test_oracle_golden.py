@@ -4,6 +4,8 @@
   * re-injected : load the reference's state at step t, take ONE step, compare with step t+1.
 Bars: masks (flags / done / game_over / num_other_agents) bit-exact; float64 quantities within 1e-9 absolute
 (north-star bar; a last-bit libm-vs-numpy difference can flip the float32 rounding of an action, a 6e-8 relative jump)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -118,3 +120,61 @@ def test_laserscan_map_and_wall_collisions():
     assert mism <= 3, mism
     assert (ep.flags[-1] & orc.IN_COLLISION).any(), "the scenario is meant to contain a wall collision"
     assert ep.laser.min() < 60 and (ep.laser == 60).any()
+
+
+# ---------------------------------------------------------------- GA3C-CADRL network (PARITY UNPINNED: no TensorFlow here)
+def test_ga3c_network_known_answers_and_checkpoint_reader():
+    """The numpy restatement of the TF graph gives the three known answers of SURVEY.md Appendix C; the package's
+    TF-free checkpoint reader and the shipped .npz agree with each other on every tensor."""
+    from oracle.ga3c_ref import ACTIONS, GA3CNet
+    from gym_collision_avoidance_amd.envs.policies.GA3C_CADRL import network
+    net = GA3CNet()
+
+    def row(num, dist, head, ps, rad, others=()):
+        r = np.zeros(6 + 7 * 19, np.float32)
+        r[1:6] = [num, dist, head, ps, rad]
+        for s, o in enumerate(others):
+            r[6 + 7 * s:13 + 7 * s] = o
+        return r
+    rows = np.array([row(0, 5, 0, 1, 0.5), row(0, 5, 0.6, 1, 0.5),
+                     row(1, 5, 0, 1, 0.5, [[2.0, 0.0, -1.0, 0.0, 0.5, 1.0, 1.0]])])
+    idx = net.action_index(rows)
+    assert list(idx) == [2, 0, 3]          # straight; hard right (heading error +0.6); veer left around a head-on agent
+    np.testing.assert_allclose(ACTIONS[idx], [[1, 0], [1, -np.pi / 6], [1, np.pi / 12]], atol=1e-12)
+    np.testing.assert_allclose(net.find_next_action(rows, [0.8, 1.0, 1.2]),
+                               [[0.8, 0], [1.0, -np.pi / 6], [1.2, np.pi / 12]], atol=1e-12)
+    p = net.predict_p(net.policy_vector(rows))
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, atol=1e-6)
+    # shorter observation rows are zero-padded (network.py:24-35): K = 3 slots give the same answer as 19
+    assert list(net.action_index(rows[:, :6 + 7 * 3])) == [2, 0, 3]
+    # a sequence_length of 0 ignores whatever sits in the other-agent slots
+    junk = rows[0].copy()
+    junk[6:] = 3.0
+    np.testing.assert_array_equal(net.logits(net.policy_vector(junk[None])), net.logits(net.policy_vector(rows[:1])))
+    assert np.array_equal(network.Actions().actions, ACTIONS)
+    w = network.load_weights(os.path.join(network.DATA_DIR, "IROS18", "network_01900000"))
+    assert w["lstm_kernel"].shape == (71, 256) and w["logits_p_kernel"].shape == (256, 11)
+    ref = "/root/reference/gym_collision_avoidance/envs/policies/GA3C_CADRL/checkpoints/IROS18/network_01900000"
+    if os.path.exists(ref + ".index"):     # in the build container: the raw TF checkpoint parses to the same arrays
+        raw = network.read_checkpoint(ref)
+        assert set(raw) == set(w)
+        for k in raw:
+            assert np.array_equal(raw[k], w[k]), k
+
+
+def test_ga3c_agents_reach_their_goals_in_the_oracle():
+    """Behavioural pin: four GA3C-CADRL agents crossing at the origin all arrive, nobody collides"""
+    from oracle import ca_oracle as orc
+    p = orc.default_params(1, 4, max_obs=19, sort_mode=orc.SORT_CLOSEST_LAST)
+    o = orc.Oracle(p)
+    o.set_policies(orc.POL_GA3C_CADRL)
+    cases = np.array([[[-3, 0, 3, 0, 1.0, 0.5], [3, 0.1, -3, 0, 1.0, 0.5], [0, -3, 0, 3, 1.0, 0.4],
+                       [0.2, 3, 0, -3, 1.0, 0.4]]], dtype=np.float64)
+    o.reset(cases)
+    for t in range(150):
+        o.step()
+        if o.game_over[0]:
+            break
+    f = o.view("flags")[0]
+    assert o.game_over[0] and t < 100
+    assert all(f & orc.AT_GOAL) and not any(f & orc.IN_COLLISION)
