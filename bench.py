@@ -7,7 +7,10 @@ cases 10_agents_500_cases with deterministic auto-reset.  One "step" = one `env.
 shard = one cagpu_step launch through the C ABI.  Weak scaling: every GPU owns 4096 envs (config 4 = 8 x 4096);
 the only collective is one RCCL all-reduce of the 8 episode counters.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout] [--workload rvo10|ga3c20|crowd50_laser]
+The default workload is the metric's; `ga3c20` (BASELINE config 3: 4096 x 20 GA3C-CADRL agents, network on the fp32
+matrix cores) and `crowd50_laser` (config 5: 4096 x 50 RVO agents + static map + LaserScanSensor) are the "next" rows,
+measured with the same harness and reported with their own roofline (profiles/).
 N>1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.
 """
@@ -23,6 +26,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md)
+# GA3C-CADRL network, multiply-adds per query with all 19 LSTM steps live
+GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
 
 
 def measured_traffic_bytes(envs, agents):
@@ -64,13 +70,62 @@ def cpu_baseline(n_agents, K, budget_s=12.0):
                       "(BASELINE.md section 2)" % (E, n_agents, steps, dt)}
 
 
+def _time_launches(fn, n, torch, dev):
+    """average duration of n back-to-back launches of fn on torch's current stream (HIP events)"""
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def extra_workload(out, a, sim, core, E, N, K, dev, torch):
+    """metric / config / roofline of the 'next'-row workloads (not the driver's default line)"""
+    n = max(20, min(a.steps, 200))
+    if a.workload == "ga3c20":
+        infer_s = _time_launches(lambda: sim.ga3c(), n, torch, dev)
+        flops = 2.0 * GA3C_MACS * E * N
+        out["metric"] = "agent-steps/sec at 4096 envs x 20 agents (GA3C-CADRL)"
+        out["dtype"] = "f32 network (f32 MFMA), f64 simulator state"
+        out["config"]["workload"] = ("configs[2]: %d envs/GPU x %d agents, GA3CCADRLPolicy (IROS18 checkpoint, LSTM-64 + "
+                                     "3 x FC-256, argmax of 11 actions) + UnicycleDynamics + OtherAgentsStatesSensor K=19 "
+                                     "closest_last, fixture n20 (reference generator, seed 0), auto-reset; one cagpu_ga3c "
+                                     "+ one cagpu_step launch per step" % (E, N))
+        out["roofline"] = {"bound": "mfma", "achieved": flops / infer_s / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "kernel": "ga3c::ga3c_kernel", "avg_launch_us": infer_s * 1e6,
+                           "algorithmic_flops_per_launch": flops, "macs_per_agent_query": GA3C_MACS,
+                           "note": "flops counted for 19 live LSTM steps per agent (every agent of a 20-agent env "
+                                   "observes 19 others); done agents are skipped by the reference but still cost a "
+                                   "tile row here"}
+    else:
+        step_s = _time_launches(lambda: sim.step(), n, torch, dev)
+        scan_s = _time_launches(lambda: sim.laserscan(), n, torch, dev)
+        b = (104 + 28 * K + 3 * 512 * 4) * E * N
+        out["metric"] = "agent-steps/sec at 4096 envs x 50 agents (RVO) + LaserScanSensor"
+        out["config"]["workload"] = ("configs[4]: %d envs/GPU x %d agents dense crowd, RVOPolicy + static map (160 x 160 "
+                                     "cells, wall collisions) + LaserScanSensor 512 beams x 60 samples x 3 scans + "
+                                     "OtherAgentsStatesSensor K=%d, fixture n50 (make_testcase_huge, seed 0), auto-reset; "
+                                     "one cagpu_step_map + one cagpu_laserscan launch per step" % (E, N, K))
+        out["roofline"] = {"bound": "hbm", "achieved": b / (step_s + scan_s) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": b / (step_s + scan_s) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "ca_kernel + scan_kernel", "avg_launch_us": (step_s + scan_s) * 1e6,
+                           "step_kernel_us": step_s * 1e6, "scan_kernel_us": scan_s * 1e6,
+                           "algorithmic_bytes_per_launch": b,
+                           "algorithmic_bytes_per_agent_step": 104 + 28 * K + 3 * 512 * 4}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--agents", type=int, default=10)
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--workload", choices=["rvo10", "ga3c20", "crowd50_laser"], default="rvo10")
     ap.add_argument("--mode", choices=["step", "rollout"], default="step",
                     help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,11 +157,21 @@ def main():
     from gym_collision_avoidance_amd import core
     from gym_collision_avoidance_amd.sharding import shard_env_ids, reduce_episode_stats
 
-    N, E = a.agents, a.envs
-    K = N - 1
+    E = a.envs
+    N = a.agents if a.agents else {"rvo10": 10, "ga3c20": 20, "crowd50_laser": 50}[a.workload]
+    K = 19 if a.workload == "ga3c20" else N - 1
     table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
-    sim = core.BatchedSim(core.make_params(E, N, max_obs=K), device=dev)
-    sim.set_plugins(nat.POL_RVO, nat.DYN_UNICYCLE)
+    sort = nat.SORT_CLOSEST_LAST if a.workload == "ga3c20" else nat.SORT_CLOSEST_FIRST
+    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort), device=dev)
+    sim.set_plugins(nat.POL_GA3C_CADRL if a.workload == "ga3c20" else nat.POL_RVO, nat.DYN_UNICYCLE)
+    if a.workload == "ga3c20":
+        sim.load_ga3c()
+    if a.workload == "crowd50_laser":  # Map(16 m, 16 m, 0.1 m) with a few wall segments + the 512-beam scan
+        grid = np.zeros((160, 160), dtype=bool)
+        grid[40:44, 30:130] = True
+        grid[116:120, 30:130] = True
+        grid[60:100, 78:82] = True
+        sim.set_map(grid)
     off, stride = shard_env_ids(rank, world, E)
     sim.set_fixture_table(table, env_id_offset=off, case_stride=stride)
     sim.reset_from_table()
@@ -114,6 +179,10 @@ def main():
     def run(n):
         if a.mode == "rollout":
             sim.rollout(n)
+        elif a.workload == "crowd50_laser":
+            for _ in range(n):
+                sim.step()
+                sim.laserscan()
         else:
             for _ in range(n):
                 sim.step()
@@ -164,7 +233,9 @@ def main():
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
         }
-        if world == 1 and a.mode == "step":
+        if a.workload != "rvo10":
+            extra_workload(out, a, sim, core, E, N, K, dev, torch)
+        if world == 1 and a.mode == "step" and a.workload == "rvo10":
             # extra: the same K steps fused into ONE cagpu_rollout launch (env_utils.run_episode's loop on the device)
             torch.cuda.synchronize(dev)
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -177,7 +248,7 @@ def main():
                               "ms_per_step": rms / a.steps, "launches": 1,
                               "note": "same workload, %d steps in one launch (state stays in registers/LDS between "
                                       "steps; observations, rewards and done flags are still written every step)" % a.steps}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "rvo10":
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))
     if world > 1:

@@ -248,16 +248,45 @@ def fixtures():
     print("fixtures ok", {k: v.shape for k, v in out.items()})
 
 
+def crowd_tables():
+    """Fixture tables for the agent counts the reference ships no pickle for, drawn ONCE with
+    the reference's own generators under a fixed seed: n20 = 500 x generate_rand_test_case_multi(20, U[6,8] m,
+    speed [0.5,2], radius [0.2,0.8]) (gen_rand_testcases.py:111-142, side lengths of config.py:57-60), n50 = 100 x
+    make_testcase_huge(50 agents, side 15 m) (test_cases.py:914-976).  Runs in a subprocess (--worker __tables__)."""
+    os.environ["GYM_CONFIG_PATH"] = os.path.join(HERE, "golden_configs.py")
+    os.environ["GYM_CONFIG_CLASS"] = "Bench10"
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path[:0] = [os.path.join(HERE, "stubs"), os.path.join(HERE, "_build"), REF]
+    import warnings
+    warnings.filterwarnings("ignore")
+    from gym_collision_avoidance.envs import test_cases as rtc
+    np.random.seed(0)
+    n20 = np.array([rtc.tc.generate_rand_test_case_multi(20, float(np.random.uniform(6, 8)), [0.5, 2.0], [0.2, 0.8])
+                    for _ in range(500)], dtype=np.float64)
+    n50 = np.asarray(rtc.make_testcase_huge(num_test_cases=100, num_agents=50, side_length=15), dtype=np.float64)
+    assert n20.shape == (500, 20, 6) and n50.shape == (100, 50, 6)
+    path = os.path.join(DATA, "test_cases.npz")
+    with np.load(path) as z:
+        out = {k: z[k] for k in z.files}
+    out["n20"], out["n50"] = n20, n50
+    np.savez_compressed(path, **out)
+    print("crowd tables ok", n20.shape, n50.shape)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--worker")
     ap.add_argument("--only", nargs="*")
     a = ap.parse_args()
+    if a.worker == "__tables__":
+        crowd_tables()
+        return
     if a.worker:
         worker(a.worker)
         return
     subprocess.check_call(["make", "-C", HERE, "-s"])
     fixtures()
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", "__tables__"])
     for name in (a.only or SCENARIOS):
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", name])
 

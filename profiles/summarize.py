@@ -11,7 +11,7 @@ import sys
 
 
 def kernel_stats(d):
-    f = glob.glob(os.path.join(d, "*kernel_stats.csv"))
+    f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     if not f:
         return
     print("## rocprofv3 --kernel-trace --stats (%s)\n" % d)
@@ -26,13 +26,13 @@ def kernel_stats(d):
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not f:
         return
     agg = collections.defaultdict(list)
     meta = {}
     for r in csv.DictReader(open(f[0])):
-        if "ca_kernel" in r["Kernel_Name"]:
+        if "ca_kernel" in r["Kernel_Name"] or "ga3c" in r["Kernel_Name"] or "scan_kernel" in r["Kernel_Name"]:
             short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",
