@@ -55,6 +55,7 @@ struct KArgs {
   const uint8_t* reset_mask;
   CaMap map;  // static obstacles for wall collisions (static_bits == NULL: none)
   int32_t n_steps, mode, stage_obs;
+  int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
   const int K = p.max_obs, W = 6 + 7 * K;
   const float inv_n = 1.0f / static_cast<float>(N);
-  const int tile_envs = ROW / N;
+  const int tile_envs = k.tile_envs;
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
@@ -554,8 +555,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           int rank = 0, cnt = 0;
           for (int q = 0; q < N; ++q) {
             const float dq = dmat[q * ROW + ag];
-            rank += (dq < dj) ? 1 : ((dq == dj) ? ((q < j) ? 1 : 0) : 0);
-            cnt += (dq < INFINITY) ? 1 : 0;
+            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
+            cnt += static_cast<int>(dq < INFINITY);
           }
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (j == aa) {
@@ -807,15 +808,24 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
             const bool vq = kq < INFINITY;
             const double tq = vq ? tmat[q * ROW + ag] : 0.0;
-            const int before = (tq > tj) ? 1 : ((tq == tj) ? ((kq > kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0)) : 0);
-            rank += (vq && vj) ? before : 0;
-            cnt += vq ? 1 : 0;
+            const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j));
+            const int lk = static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo);
+            const int before = static_cast<int>(tq > tj) | (static_cast<int>(tq == tj) & lk);
+            rank += static_cast<int>(vq) & static_cast<int>(vj) & before;
+            cnt += static_cast<int>(vq);
           }
         } else {
+          // branch-free on purpose: both keys are loaded unconditionally and the lexicographic (key, p_orth, index)
+          // test is combined with bitwise operators, so the unrolled loop is 2 LDS reads + 4 compares per candidate
+          // with one wait for all of them (the short-circuit form compiled to a chain of dependent LDS round trips
+          // and ~10 taken branches per item)
           for (int q = 0; q < N; ++q) {
             const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-            rank += (kq < kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((q < j) ? 1 : 0) : 0)) : 0);
-            cnt += (kq < INFINITY) ? 1 : 0;
+            const int before = static_cast<int>(kq < kj) |
+                               (static_cast<int>(kq == kj) &
+                                (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j))));
+            rank += before;
+            cnt += static_cast<int>(kq < INFINITY);
           }
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
@@ -858,9 +868,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           int r2 = 0;
           for (int q = 0; q < N; ++q) {
             const int rq = rmat[q * ROW + ag];
-            if (rq >= N) continue;
             const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-            r2 += (kq > kj) ? 1 : ((kq == kj) ? ((oq < oj) ? 1 : ((oq == oj) ? ((rq < rank) ? 1 : 0) : 0)) : 0);
+            const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(rq < rank));
+            r2 += static_cast<int>(rq < N) & (static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo));
           }
           float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
@@ -1073,7 +1083,7 @@ int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int tile_envs = ROW / k.p.num_agents;
+  const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
   hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
@@ -1143,9 +1153,15 @@ int launch_g16(const KArgs& k, hipStream_t st) {
 //     fit a CU and all 683 workgroups are co-resident: 256 threads -> 48 us, 128 -> 55, 384/512 -> 63.
 //   n-step rollout: the in-kernel step loop costs ~235 VGPRs (2 waves/SIMD): 128 threads -> 36.7 us/step, 256 -> 54.
 // CAGPU_NT overrides for experiments.
-int launch_any(const KArgs& k, void* stream) {
+int launch_any(const KArgs& k0, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  KArgs k = k0;
   const int N = k.p.num_agents;
+  k.tile_envs = ROW / N;
+  if (const char* e = std::getenv("CAGPU_TILE")) {  // experiments
+    const int t = std::atoi(e);
+    if (t >= 1 && t < k.tile_envs) k.tile_envs = t;
+  }
   if (N <= G16 && std::getenv("CAGPU_G16") && k.p.sort_mode != CA_SORT_TIME_TO_IMPACT && !k.map.static_bits) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
     const bool multi = k.mode == MODE_STEP && k.n_steps > 1;
     if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
