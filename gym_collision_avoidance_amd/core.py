@@ -164,8 +164,17 @@ class BatchedSim(object):
         t = self._dev(table, torch.float64)
         assert t.dim() == 3 and t.shape[1:] == (self.N, 6), t.shape
         self._table = t
-        self._ar = nat.CaAutoReset(table=t.data_ptr(), n_cases=int(t.shape[0]), env_id_offset=int(env_id_offset),
-                                   case_stride=int(self.E if case_stride is None else case_stride))
+        # the reset observation of every case, computed once by the reset kernel itself on a scratch batch of C envs
+        C_ = int(t.shape[0])
+        ps = nat.CaParams.from_buffer_copy(self.p)
+        ps.num_envs = C_
+        scratch = BatchedSim(ps, device=self.device)
+        scratch.reset(t)
+        self._reset_obs = scratch.obs
+        torch.cuda.current_stream(self.device).synchronize()
+        self._ar = nat.CaAutoReset(table=t.data_ptr(), n_cases=C_, env_id_offset=int(env_id_offset),
+                                   case_stride=int(self.E if case_stride is None else case_stride),
+                                   reset_obs=self._reset_obs.data_ptr())
 
     # ---------------------------------------------------------------- the C-ABI calls
     def reset(self, cases, headings=None, mask=None):

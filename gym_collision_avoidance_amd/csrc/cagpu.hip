@@ -49,6 +49,7 @@ struct KArgs {
   const double* table;
   int32_t n_cases;
   int64_t env_id_offset, case_stride;
+  const float* reset_obs;  // [n_cases, N, W] reset observation of every case (nullptr: re-sense after an auto-reset)
   // explicit reset
   const double* reset_cases;
   const double* reset_headings;
@@ -382,7 +383,7 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO>
 __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         sh_fvy[lane] = static_cast<float>(r.vy);
         sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
         sh_q[lane] = rvo ? 1 : 0;
+        sh_sense[lane] = 0;  // [0]: length of the linearProgram3 queue, [1..]: its entries (dead as sense flags here)
         if (rvo) {
           const double vx = r.gx - r.px, vy = r.gy - r.py;
           const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
@@ -589,11 +591,30 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             const float ms = sh_fms[agf];
             F2 v;
             const int failf = lp2_group(valid, P, D, ms, f2(sh_fprx[agf], sh_fpry[agf]), false, v, jl, tid & 63);
-            if (failf != NOFAIL) lp3_group(nf, failf, P, D, ms, v, jl, tid & 63);
-            if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
+            if (jl == 0) {
+              sh_vrx[agf] = v.x;
+              sh_vry[agf] = v.y;
+              // infeasible (4.6 % of the queries): queue the agent for the linearProgram3 pass below instead of
+              // solving it here, where it would stall the three sibling groups of this wave for ~10 k cycles
+              if (failf != NOFAIL) sh_sense[1 + atomicAdd(&sh_sense[0], 1)] = agf | (failf << 8);
+            }
           }
         }
         __syncthreads();
+        const int n3 = any_rvo ? sh_sense[0] : 0;
+        if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+          // queue entry k goes to wave k % (number of waves) first: infeasible agents are solved side by side
+          const int jl = tid & 15, g = tid >> 4;
+          for (int q3 = (g & 3) * (NT / 64) + (g >> 2); q3 < n3; q3 += NT / 16) {
+            const int ent = sh_sense[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
+            const int nf = sh_nb[agf];
+            const float4 ln = Lmat[((jl < nf) ? jl : 0) * ROW + agf];
+            F2 v = f2(sh_vrx[agf], sh_vry[agf]);
+            lp3_group(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
+            if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
+          }
+          __syncthreads();
+        }
       } else if (wave0 && rvo) {
         const F2 pref = f2(sh_fprx[lane], sh_fpry[lane]);
         const float ms = sh_fms[lane];
@@ -713,6 +734,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           sh_pry[lane] = eg.pry;
         }
         sh_sense[lane] = do_sense ? 1 : 0;
+        if (RO) sh_q[lane] = 0;  // reused below: case index + 1 of an env that auto-resets in this step
       }
       __syncthreads();
       TICK(6);
@@ -895,15 +917,17 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       if (k.mode == MODE_STEP && pass == 0) {
         do_sense = false;
         if (wave0 && active) {
-          bool all_done = true, all_learning_done = true, any_coll = false, all_goal = true;
+          // AND / OR of the env's flag words, then bit tests: no short-circuit chains (they compile to one dependent
+          // LDS round trip + branch per agent)
+          uint32_t f_and = ~0u, f_or = 0u, learn_and = ~0u;
           for (int j = 0; j < N; ++j) {
             const uint32_t f = sh_flag[ebase + j];
-            const bool dj = (f & CA_DONE) != 0;
-            all_done = all_done && dj;
-            if (f & CA_STILL_LEARNING) all_learning_done = all_learning_done && dj;
-            any_coll = any_coll || (f & CA_IN_COLLISION);
-            all_goal = all_goal && (f & CA_AT_GOAL);
+            f_and &= f;
+            f_or |= f;
+            learn_and &= (f & CA_STILL_LEARNING) ? f : ~0u;  // learners only
           }
+          const bool all_done = (f_and & CA_DONE) != 0, all_learning_done = (learn_and & CA_DONE) != 0;
+          const bool any_coll = (f_or & CA_IN_COLLISION) != 0, all_goal = (f_and & CA_AT_GOAL) != 0;
           bool over = all_done;
           if (p.game_over_mode == CA_OVER_AGENT0) over = (sh_flag[ebase] & CA_DONE) != 0;
           else if (p.game_over_mode == CA_OVER_LEARNING_DONE) over = all_learning_done;
@@ -933,14 +957,34 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             reset_lane(r, k.table + (c * N + a) * 6, nullptr, p);
             ep_step = 0;
             statics_dirty = true;
-            do_sense = true;
+            if (RO) {
+              if (a == 0) sh_q[lane] = static_cast<int>(c) + 1;  // the env's new case, at its first agent's slot
+            } else {
+              do_sense = true;
+            }
             need_second = true;
           }
         }
       }
       const int again = __syncthreads_or(need_second ? 1 : 0);
       TICK(10);
-      if (!again) {
+      if (RO && again) {
+        // ---- RO: the observation of a freshly reset env is a pure function of its fixture case: it was computed once
+        // (cagpu_reset on the whole table) and is copied here, instead of a second sensing pass for the tile
+        for (long q = tid; q < tile_cnt * W; q += NT) {
+          const int ag = static_cast<int>(q / W), col = static_cast<int>(q - static_cast<long>(ag) * W);
+          const int eb2 = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N;
+          const int c1 = sh_q[eb2];
+          if (c1) {
+            float v = k.reset_obs[(static_cast<long>(c1 - 1) * N + (ag - eb2)) * W + col];
+            if (col == 0) v = (sh_flag[ag] & CA_IS_LEARNING) ? 1.f : 0.f;
+            if (STAGE) sh_obs[q] = v;
+            else k.o.obs[tile_base * W + q] = v;
+          }
+        }
+        __syncthreads();
+      }
+      if (RO || !again) {
         // ---- the tile's observation block leaves LDS as one contiguous, coalesced copy
         if (STAGE && !AB(128)) {
           const long total = tile_cnt * W;
@@ -962,7 +1006,11 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       }
       return 1;  // some env of the tile auto-reset: run the sensing pass once more for it
     };
-    if (sense_pass(0)) sense_pass(1);
+    if (RO) {
+      sense_pass(0);
+    } else if (sense_pass(0)) {
+      sense_pass(1);
+    }
     __syncthreads();  // the union is free again before the next step's ORCA view
     TICK(11);
   };
@@ -1076,19 +1124,25 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI>
-int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO>
+int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI>), dim3(grid), dim3(NT), total, st, k);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
+}
+
+template <int NT, bool STAGE, int NC, bool MULTI>
+int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
+  if (k.mode == MODE_STEP && k.table && k.reset_obs) return launch_main5<NT, STAGE, NC, MULTI, true>(k, total, st);
+  return launch_main5<NT, STAGE, NC, MULTI, false>(k, total, st);
 }
 
 template <int NT, bool STAGE, int NC>
@@ -1172,9 +1226,7 @@ int launch_any(const KArgs& k0, void* stream) {
   int nt = (k.mode == MODE_STEP && k.n_steps > 1) ? 128 : 256;
   if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
   if (nt <= 128) return launch_main<128>(k, st);
-  if (nt <= 256) return launch_main<256>(k, st);
-  if (nt <= 384) return launch_main<384>(k, st);
-  return launch_main<512>(k, st);
+  return launch_main<256>(k, st);
 }
 
 int pick_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : 256); }
@@ -1229,6 +1281,7 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
   if (ar) {
     if (!ar->table || ar->n_cases < 1) return fail(CA_EINVAL, "cagpu: bad CaAutoReset%s");
     k.table = ar->table; k.n_cases = ar->n_cases; k.env_id_offset = ar->env_id_offset; k.case_stride = ar->case_stride;
+    k.reset_obs = ar->reset_obs;
   }
   if (map && map->static_bits) {
     if (map->rows < 1 || map->cols < 1 || !(map->cell > 0.0)) return fail(CA_EINVAL, "cagpu: bad CaMap%s");

@@ -129,6 +129,9 @@ typedef struct CaAutoReset {
   int32_t n_cases;
   int64_t env_id_offset; /* global id of this shard's env 0 (multi-GPU sharding) */
   int64_t case_stride;   /* normally the global number of envs */
+  const float *reset_obs; /* device float [n_cases, N, 6+7*max_obs] or NULL: the reset observation of every case,
+                             i.e. o->obs of cagpu_reset(num_envs = n_cases, cases = table) with the same CaParams.
+                             With it an auto-reset copies the row; without it the tile runs a second sensing pass. */
 } CaAutoReset;
 
 /* Static occupancy grid shared by every env (Map.py:6-24; the env builds Map(16 m, 16 m, 0.1 m), env.py:378-392).

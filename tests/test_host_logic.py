@@ -36,7 +36,7 @@ def test_ctypes_structs_match_header_layout():
     from gym_collision_avoidance_amd import _native as nat
     assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 15 * 8
     assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
-    assert ctypes.sizeof(nat.CaAutoReset) == 32
+    assert ctypes.sizeof(nat.CaAutoReset) == 40 and nat.CaAutoReset.reset_obs.offset == 32
     assert nat.CaParams.dt.offset == 32
     assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
     assert ctypes.sizeof(nat.CaScan) == 2 * 8 + 4 * 4 + 4 * 8 and nat.CaScan.min_angle.offset == 32
