@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
   const int K = p.max_obs, W = 6 + 7 * K;
   const float inv_n = 1.0f / static_cast<float>(N);
-  const int tile_envs = k.tile_envs;
+  const int tile_envs = (NC && !MULTI) ? ROW / (NC ? NC : 1) : k.tile_envs;  // compile-time in the specialised kernel
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       if (any_rvo && !AB(1)) {
         // ================= P1: squared centre distances of every (agent, other) pair (Agent::insertAgentNeighbor)
         const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
+#pragma unroll
         for (int w = tid; w < n_items; w += NT) {
           const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
           const int j = w - ag * N;
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         const float inv_h = divf(1.0f, static_cast<float>(p.rvo_time_horizon));
         const float ts = static_cast<float>(p.dt);
         const float collab = static_cast<float>(p.rvo_collab_coeff);
+#pragma unroll
         for (int w = tid; w < n_items; w += NT) {
           const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
           const int j = w - ag * N;
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
 
       // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
       //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
+#pragma unroll
       for (int w = tid; w < n_items && !AB(32); w += NT) {
         const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
         const int j = w - ag * N;
@@ -816,6 +819,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
 
       TICK(8);
       // ---- P4: rank the candidates of every agent and emit its rows (OtherAgentsStatesSensor.py:20-55,109-143)
+#pragma unroll
       for (int w = tid; w < n_items && !AB(64); w += NT) {
         const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
         const int j = w - ag * N;
@@ -1153,7 +1157,8 @@ int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
 
 template <int NT, bool STAGE>
 int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
-  if (STAGE && k.p.num_agents == 10 && !std::getenv("CAGPU_NO_NC")) return launch_main3<NT, STAGE, 10>(k, total, st);
+  if (STAGE && k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
+    return launch_main3<NT, STAGE, 10>(k, total, st);  // N and the tile size compiled in
   return launch_main3<NT, STAGE, 0>(k, total, st);
 }
 
