@@ -975,15 +975,17 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       if (RO && again) {
         // ---- RO: the observation of a freshly reset env is a pure function of its fixture case: it was computed once
         // (cagpu_reset on the whole table) and is copied here, instead of a second sensing pass for the tile
-        for (long q = tid; q < tile_cnt * W; q += NT) {
-          const int ag = static_cast<int>(q / W), col = static_cast<int>(q - static_cast<long>(ag) * W);
-          const int eb2 = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N;
-          const int c1 = sh_q[eb2];
-          if (c1) {
-            float v = k.reset_obs[(static_cast<long>(c1 - 1) * N + (ag - eb2)) * W + col];
-            if (col == 0) v = (sh_flag[ag] & CA_IS_LEARNING) ? 1.f : 0.f;
-            if (STAGE) sh_obs[q] = v;
-            else k.o.obs[tile_base * W + q] = v;
+        for (int le2 = 0; le2 < tile_envs; ++le2) {  // workgroup-uniform: at most a few envs of a tile reset per step
+          const int c1 = sh_q[le2 * N];
+          if (!c1) continue;
+          const float* src = k.reset_obs + static_cast<long>(c1 - 1) * N * W;
+          const int base = le2 * N * W;
+          for (int q = tid; q < N * W; q += NT) {
+            const int a2 = q / W, col = q - a2 * W;
+            float v = src[q];
+            if (col == 0) v = (sh_flag[le2 * N + a2] & CA_IS_LEARNING) ? 1.f : 0.f;
+            if (STAGE) sh_obs[base + q] = v;
+            else k.o.obs[tile_base * W + base + q] = v;
           }
         }
         __syncthreads();
