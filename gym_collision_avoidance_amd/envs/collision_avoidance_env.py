@@ -94,11 +94,14 @@ class CollisionAvoidanceEnv(Env):
         self._fixture = None
 
     def set_fixture_suite(self, num_agents, policies="RVO", agents_dynamics="unicycle", auto_reset=True,
-                          env_id_offset=0, case_stride=None):
+                          env_id_offset=0, case_stride=None, table=None):
         """Batched evaluation on the reference's 500-case suite (run_full_test_suite.py:54-130): env e starts on case
         (env_id_offset + e) % 500 and, with auto_reset, its k-th episode loads case (env_id_offset + e + k*stride) % 500
         on the device (DummyVecEnv semantics, vec_env.py:120-128)."""
-        table = tc.fixture_table(num_agents)
+        # `table`: any float64 [C, num_agents, 6] case table instead of the reference's 500-case pickle, e.g. C scenarios
+        # drawn with envs/scenario_generator.py for on-device auto-reset during training
+        table = tc.fixture_table(num_agents) if table is None else np.ascontiguousarray(table, dtype=np.float64)
+        assert table.ndim == 3 and table.shape[1:] == (num_agents, 6), table.shape
         self._fixture = dict(table=table, policies=policies, dynamics=agents_dynamics, auto_reset=auto_reset,
                              env_id_offset=env_id_offset,
                              case_stride=self.num_envs if case_stride is None else case_stride)
@@ -182,7 +185,11 @@ class CollisionAvoidanceEnv(Env):
                                                        agents_dynamics=f["dynamics"])
         else:
             if self.default_agents is None:
-                agents = self.test_case_fn(**self.test_case_args)
+                if E > 1 and self.test_case_args.get("num_agents") is not None:
+                    # batched + a scenario function with a fixed agent count: every env draws its own scenario
+                    agents = [self.test_case_fn(**self.test_case_args) for _ in range(E)]
+                else:
+                    agents = self.test_case_fn(**self.test_case_args)
             else:
                 agents = self.default_agents
             if len(agents) and isinstance(agents[0], (list, tuple)):

@@ -4,8 +4,8 @@ Covered: the registries (`policy_dict`, `sensor_dict`, `dynamics_dict`, test_cas
 (`preset_testCases(n, full_test_suite=True)`, :593-624 -- shipped as data/test_cases.npz, converted from the reference's
 pickles by oracle/gen_golden.py), `cadrl_test_case_to_agents` (:495-590), `full_test_suite` (:593+ plumbing used by
 run_full_test_suite), `get_testcase_two_agents` (:144-175), `gen_circle_test_case` (:900-911) and the hand-written
-small presets.  Random scenario generation (`get_testcase_random`, gen_rand_testcases.py) is a "next" row of
-SURVEY.md section 8(f) and raises NotImplementedError.
+small presets, and random scenario generation (`get_testcase_random` -> scenario_generator.py, bit-identical to
+gen_rand_testcases.py under the same np.random seed).
 """
 import os
 
@@ -130,6 +130,22 @@ def get_testcase_two_agents(policies=("learning", "GA3C_CADRL")):
                   [OtherAgentsStatesSensor], 1)]
 
 
-def get_testcase_random(*args, **kwargs):
-    raise NotImplementedError("random scenario generation (gen_rand_testcases.py:111-444) is a 'next' row of "
-                              "SURVEY.md section 8(f); use set_agents / the fixture suite")
+def get_testcase_random(num_agents=None, side_length=4, speed_bnds=[0.5, 2.0], radius_bnds=[0.2, 0.8],
+                        policies="learning", policy_distr=None, agents_dynamics="unicycle",
+                        agents_sensors=["other_agents_states"], policy_to_ensure=None, prev_agents=None):
+    """A random scenario (the reference's default TEST_CASE_FN, test_cases.py:212-253): 2 .. MAX_NUM_AGENTS agents,
+    world size drawn from the {num_agents range: side_length range} list, 15 % swap / 15 % circle / 70 % rejection-
+    sampled random starts and goals (scenario_generator.py).  Same np.random draws as the reference: under the same
+    seed the scenario is the reference's, bit for bit."""
+    from gym_collision_avoidance_amd.envs import scenario_generator
+    if num_agents is None:
+        num_agents = np.random.randint(2, Config.MAX_NUM_AGENTS_IN_ENVIRONMENT + 1)
+    if type(side_length) is list:
+        for comp in side_length:
+            if comp["num_agents"][0] <= num_agents < comp["num_agents"][1]:
+                side_length = np.random.uniform(comp["side_length"][0], comp["side_length"][1])
+        assert type(side_length) == float
+    case = scenario_generator.generate_rand_test_case_multi(num_agents, side_length, speed_bnds, radius_bnds)
+    return cadrl_test_case_to_agents(case, policies=policies, policy_distr=policy_distr,
+                                     agents_dynamics=agents_dynamics, agents_sensors=agents_sensors,
+                                     policy_to_ensure=policy_to_ensure, prev_agents=prev_agents)

@@ -273,6 +273,38 @@ def crowd_tables():
     print("crowd tables ok", n20.shape, n50.shape)
 
 
+def rand_cases():
+    """Known answers for the random scenario generator: the reference's generate_rand_test_case_multi and
+    get_testcase_random (TRAIN config: random agent count, side-length table, random headings) under fixed seeds.
+    Runs in a subprocess (--worker __rand__)."""
+    os.environ["GYM_CONFIG_PATH"] = os.path.join(HERE, "golden_configs.py")
+    os.environ["GYM_CONFIG_CLASS"] = "Train5"
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path[:0] = [os.path.join(HERE, "stubs"), os.path.join(HERE, "_build"), REF]
+    import warnings
+    warnings.filterwarnings("ignore")
+    from gym_collision_avoidance.envs import Config
+    from gym_collision_avoidance.envs import test_cases as rtc
+    out = {}
+    for seed in range(60):          # the three families at assorted sizes
+        n, side = 2 + seed % 9, 4.0 + (seed % 5)
+        np.random.seed(seed)
+        out["multi_%d" % seed] = np.asarray(rtc.tc.generate_rand_test_case_multi(n, side, [0.5, 2.0], [0.2, 0.8]))
+    args = dict(Config.TEST_CASE_ARGS)
+    for seed in range(20):          # the env's default reset path (collision_avoidance_env.py:345-362)
+        np.random.seed(1000 + seed)
+        agents = rtc.get_testcase_random(**args)
+        out["env_%d" % seed] = np.array([[a.pos_global_frame[0], a.pos_global_frame[1], a.goal_global_frame[0],
+                                          a.goal_global_frame[1], a.pref_speed, a.radius, a.heading_global_frame]
+                                         for a in agents])
+        out["envpol_%d" % seed] = np.array([type(a.policy).__name__ for a in agents])
+    out["max_agents"] = np.array(Config.MAX_NUM_AGENTS_IN_ENVIRONMENT)
+    import json
+    out["test_case_args"] = np.array(json.dumps({k: v for k, v in args.items()}, default=lambda o: float(o) if o == np.inf else str(o)))
+    np.savez_compressed(os.path.join(GOLD, "rand_cases.npz"), **out)
+    print("rand cases ok", len(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--worker")
@@ -281,12 +313,16 @@ def main():
     if a.worker == "__tables__":
         crowd_tables()
         return
+    if a.worker == "__rand__":
+        rand_cases()
+        return
     if a.worker:
         worker(a.worker)
         return
     subprocess.check_call(["make", "-C", HERE, "-s"])
     fixtures()
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", "__tables__"])
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", "__rand__"])
     for name in (a.only or SCENARIOS):
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", name])
 
