@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "cagpu.h"
 
@@ -349,9 +350,10 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 
 // fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
 __host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 10 * 4 + 4 * 4); }
-// union, ORCA view: dist^2 [N][ROW] f32, lines + projected lines [N-1][ROW] float4 each
+// union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
+// the registers of the solving group)
 __host__ __device__ inline size_t lds_orca_bytes(int N) {
-  return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * 2 * (N > 1 ? N - 1 : 1) * 16;
+  return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * (N > 1 ? N - 1 : 1) * 16;
 }
 // union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] i32,
 // obs staging [ROW*W] f32
@@ -436,7 +438,6 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   // ORCA view of the union
   float* dmat = reinterpret_cast<float*>(un);                                   // [N][ROW]
   float4* Lmat = reinterpret_cast<float4*>(un + static_cast<size_t>(ROW) * N * 4);  // [N-1][ROW]
-  float4* Pmat = Lmat + static_cast<size_t>(N > 1 ? N - 1 : 1) * ROW;
   // sensor view of the union
   double* kmat = reinterpret_cast<double*>(un);          // [N][ROW] sort key = rint(100 * dist_2_other)
   double* omat = kmat + static_cast<size_t>(N) * ROW;    // [N][ROW] p_orth
@@ -580,54 +581,53 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
       //            costs O(#violated lines) group steps instead of a serial O(n^2) walk through LDS, and the 4.6 % of
       //            queries that fall through to linearProgram3 (94 % of the 60-agent tiles hold at least one) no
       //            longer stall the other 59 lanes of a wave;
-      //   N  > 16: one lane per agent on wave 0, serial over its lines in LDS.
-      if (N <= G16) {
-        if (any_rvo && !AB(2)) {
-          const int jl = tid & 15;
-          for (int agf = tid >> 4; agf < tile_n; agf += NT / 16) {
-            if (!sh_q[agf]) continue;
-            const int nf = sh_nb[agf];
-            const bool valid = jl < nf;
-            const float4 ln = Lmat[(valid ? jl : 0) * ROW + agf];
-            const F2 P = f2(ln.x, ln.y), D = f2(ln.z, ln.w);
-            const float ms = sh_fms[agf];
-            F2 v;
-            const int failf = lp2_group(valid, P, D, ms, f2(sh_fprx[agf], sh_fpry[agf]), false, v, jl, tid & 63);
-            if (jl == 0) {
-              sh_vrx[agf] = v.x;
-              sh_vry[agf] = v.y;
-              // infeasible (4.6 % of the queries): queue the agent for the linearProgram3 pass below instead of
-              // solving it here, where it would stall the three sibling groups of this wave for ~10 k cycles
-              if (failf != NOFAIL) sh_sense[1 + atomicAdd(&sh_sense[0], 1)] = agf | (failf << 8);
+      //   N  > 16: the same with one WAVE per agent (lane j = half-plane j, N - 1 <= 63): row reductions by DPP, the
+      //            four rows combined with two xor shuffles.
+      {
+        // one group per agent: 16 lanes while N <= 16 (four agents per wave side by side), the whole wave otherwise
+        auto solve = [&](auto gs_tag) {
+          constexpr int GS = decltype(gs_tag)::value;
+          constexpr int GROUPS = NT / GS;
+          if (any_rvo && !AB(2)) {
+            const int jl = tid & (GS - 1);
+            for (int agf = tid / GS; agf < tile_n; agf += GROUPS) {
+              if (!sh_q[agf]) continue;
+              const int nf = sh_nb[agf];
+              const bool valid = jl < nf;
+              const float4 ln = Lmat[(valid ? jl : 0) * ROW + agf];
+              const F2 P = f2(ln.x, ln.y), D = f2(ln.z, ln.w);
+              const float ms = sh_fms[agf];
+              F2 v;
+              const int failf = lp2_group<GS>(valid, P, D, ms, f2(sh_fprx[agf], sh_fpry[agf]), false, v, jl, tid & 63);
+              if (jl == 0) {
+                sh_vrx[agf] = v.x;
+                sh_vry[agf] = v.y;
+                // infeasible (4.6 % of the queries at N = 10): queue the agent for the linearProgram3 pass below instead
+                // of solving it here, where it would stall the sibling groups of this wave for ~10 k cycles
+                if (failf != NOFAIL) sh_sense[1 + atomicAdd(&sh_sense[0], 1)] = agf | (failf << 8);
+              }
             }
           }
-        }
-        __syncthreads();
-        const int n3 = any_rvo ? sh_sense[0] : 0;
-        if (n3 > 0 && !AB(2)) {  // workgroup-uniform
-          // queue entry k goes to wave k % (number of waves) first: infeasible agents are solved side by side
-          const int jl = tid & 15, g = tid >> 4;
-          for (int q3 = (g & 3) * (NT / 64) + (g >> 2); q3 < n3; q3 += NT / 16) {
-            const int ent = sh_sense[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
-            const int nf = sh_nb[agf];
-            const float4 ln = Lmat[((jl < nf) ? jl : 0) * ROW + agf];
-            F2 v = f2(sh_vrx[agf], sh_vry[agf]);
-            lp3_group(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
-            if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
-          }
           __syncthreads();
-        }
-      } else if (wave0 && rvo) {
-        const F2 pref = f2(sh_fprx[lane], sh_fpry[lane]);
-        const float ms = sh_fms[lane];
-        const int n = sh_nb[lane];
-        F2 v;
-        const int fail = lp2<ROW>(Lmat + lane, n, ms, pref, false, v);
-        if (fail < n) lp3<ROW>(Lmat + lane, Pmat + lane, n, fail, ms, v);
-        sh_vrx[lane] = v.x;
-        sh_vry[lane] = v.y;
+          const int n3 = any_rvo ? sh_sense[0] : 0;
+          if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+            // queue entry k goes to wave k % (number of waves) first: infeasible agents are solved side by side
+            const int jl = tid & (GS - 1), g = tid / GS;
+            constexpr int GPW = 64 / GS;  // groups per wave
+            for (int q3 = (g % GPW) * (NT / 64) + (g / GPW); q3 < n3; q3 += GROUPS) {
+              const int ent = sh_sense[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
+              const int nf = sh_nb[agf];
+              const float4 ln = Lmat[((jl < nf) ? jl : 0) * ROW + agf];
+              F2 v = f2(sh_vrx[agf], sh_vry[agf]);
+              lp3_group<GS>(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
+              if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
+            }
+            __syncthreads();
+          }
+        };
+        if (N <= G16) solve(std::integral_constant<int, 16>{});
+        else solve(std::integral_constant<int, 64>{});
       }
-      if (N > G16) __syncthreads();
       TICK(12);
       TICK(3);
       // ================= A2c: policy post-processing (env.py:305-323) and move (agent.py:192-241), one lane per agent
@@ -1159,8 +1159,10 @@ int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
 
 template <int NT, bool STAGE>
 int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
-  if (STAGE && k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
-    return launch_main3<NT, STAGE, 10>(k, total, st);  // N and the tile size compiled in
+  if constexpr (NT <= 256) {  // the 512-thread geometry exists for large N only
+    if (STAGE && k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
+      return launch_main3<NT, STAGE, 10>(k, total, st);  // N and the tile size compiled in
+  }
   return launch_main3<NT, STAGE, 0>(k, total, st);
 }
 
@@ -1232,8 +1234,12 @@ int launch_any(const KArgs& k0, void* stream) {
   (void)items;
   int nt = (k.mode == MODE_STEP && k.n_steps > 1) ? 128 : 256;
   if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
+  // N > 32: the tile is a single env whose N^2 pair items (and N wave-wide linear programs) keep 8 waves busy, and
+  // its LDS footprint allows only one or two workgroups per CU anyway
+  if (N > 32 && !std::getenv("CAGPU_NT")) nt = 512;
   if (nt <= 128) return launch_main<128>(k, st);
-  return launch_main<256>(k, st);
+  if (nt <= 256) return launch_main<256>(k, st);
+  return launch_main<512>(k, st);
 }
 
 int pick_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : 256); }
