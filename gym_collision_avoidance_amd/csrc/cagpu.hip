@@ -349,16 +349,16 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 #include "cagpu_ga3c.inc"
 
 // fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
-__host__ __device__ inline size_t lds_fixed_bytes() { return static_cast<size_t>(ROW) * (10 * 8 + 10 * 4 + 4 * 4); }
+__host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static_cast<size_t>(row) * (10 * 8 + 10 * 4 + 4 * 4); }
 // union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
 // the registers of the solving group)
-__host__ __device__ inline size_t lds_orca_bytes(int N) {
-  return static_cast<size_t>(ROW) * N * 4 + static_cast<size_t>(ROW) * (N > 1 ? N - 1 : 1) * 16;
+__host__ __device__ inline size_t lds_orca_bytes(int N, int row = ROW) {
+  return static_cast<size_t>(row) * N * 4 + static_cast<size_t>(row) * (N > 1 ? N - 1 : 1) * 16;
 }
 // union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] i32,
 // obs staging [ROW*W] f32
-__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti) {
-  return static_cast<size_t>(ROW) * N * ((tti ? 5 : 4) * 8 + 4) + (stage ? align16(static_cast<size_t>(ROW) * W * 4) : 0);
+__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti, int row = ROW) {
+  return static_cast<size_t>(row) * N * ((tti ? 5 : 4) * 8 + 4) + (stage ? align16(static_cast<size_t>(row) * W * 4) : 0);
 }
 
 struct Lane {  // per-lane registers of one agent (wave 0)
@@ -385,8 +385,9 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64>
 __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
+  constexpr int ROW = RW;  // agent slots of the tile (shadows the default): 64, or 32 for half-size tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   float* sh_fms = sh_vry + ROW;                       // its speed limit (float pref_speed)
   float* sh_fprx = sh_fms + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
-  unsigned char* un = smem + lds_fixed_bytes();
+  unsigned char* un = smem + lds_fixed_bytes(ROW);
   // ORCA view of the union
   float* dmat = reinterpret_cast<float*>(un);                                   // [N][ROW]
   float4* Lmat = reinterpret_cast<float4*>(un + static_cast<size_t>(ROW) * N * 4);  // [N-1][ROW]
@@ -1130,16 +1131,16 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64>
 int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, RW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO>), dim3(grid), dim3(NT), total, st, k);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, RW>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
@@ -1230,8 +1231,6 @@ int launch_any(const KArgs& k0, void* stream) {
     if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
     return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);
   }
-  const int items = (ROW / N) * N * N;
-  (void)items;
   int nt = (k.mode == MODE_STEP && k.n_steps > 1) ? 128 : 256;
   if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
   // N > 32: the tile is a single env whose N^2 pair items (and N wave-wide linear programs) keep 8 waves busy, and
