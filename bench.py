@@ -248,6 +248,33 @@ def main():
                               "ms_per_step": rms / a.steps, "launches": 1,
                               "note": "same workload, %d steps in one launch (state stays in registers/LDS between "
                                       "steps; observations, rewards and done flags are still written every step)" % a.steps}
+        if world == 1 and a.mode == "step" and a.workload == "rvo10" and E % 2 == 0:
+            # extra: the same batch as two half-batches on two HIP streams (envs are independent): the tail of one
+            # launch -- a launch ends with its slowest workgroup -- overlaps with the body of the other
+            halves, streams = [], [torch.cuda.Stream(device=dev) for _ in range(2)]
+            for h in range(2):
+                sh = core.BatchedSim(core.make_params(E // 2, N, max_obs=K), device=dev)
+                sh.set_plugins(nat.POL_RVO, nat.DYN_UNICYCLE)
+                sh.set_fixture_table(table, env_id_offset=off + h * (E // 2), case_stride=stride)
+                sh.reset_from_table()
+                halves.append(sh)
+
+            def run2(n):
+                for _ in range(n):
+                    for sh, st_ in zip(halves, streams):
+                        with torch.cuda.stream(st_):
+                            sh.step()
+            run2(a.warmup)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            run2(a.steps)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter() - t2
+            out["two_streams"] = {"value": E * N * a.steps / t2, "unit": "agent-steps/s", "ms_per_step": t2 * 1e3 / a.steps,
+                                  "launches_per_step": 2,
+                                  "note": "same workload as 2 x %d envs on 2 HIP streams, host wall clock; not the headline "
+                                          "(per-launch durations overlap, so the roofline above is quoted for the "
+                                          "single-stream launch)" % (E // 2)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "rvo10":
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))
