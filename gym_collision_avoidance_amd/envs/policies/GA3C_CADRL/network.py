@@ -146,8 +146,18 @@ def read_checkpoint(prefix):
     return out
 
 
+_cache = {}
+
+
 def load_weights(path):
-    """`path`: '<...>.npz', or a prefix that has '<prefix>.npz' or '<prefix>.index' next to it."""
+    """`path`: '<...>.npz', or a prefix that has '<prefix>.npz' or '<prefix>.index' next to it.  Cached per path: a
+    500-case suite builds thousands of policy objects that all name the same checkpoint."""
+    if path not in _cache:
+        _cache[path] = _load_weights(path)
+    return _cache[path]
+
+
+def _load_weights(path):
     if path.endswith(".npz") or os.path.exists(path + ".npz"):
         with np.load(path if path.endswith(".npz") else path + ".npz") as z:
             return {k: z[k] for k in z.files}

@@ -43,3 +43,17 @@ def run_episode(env, max_steps=100000):
 def store_stats(df, hyperparameters, episode_stats):
     import pandas as pd
     return pd.concat([df, pd.DataFrame([{**hyperparameters, **episode_stats}])], ignore_index=True)
+
+
+# Named policy configurations (env_utils.py:102-492).  The reference's other GA3C-CADRL entries point at checkpoint
+# directories outside its repository; the ones below are the checkpoints it ships.
+_GA3C = {"policy": "GA3C_CADRL", "sensors": ["other_agents_states"]}
+policies = {
+    "GA3C-CADRL-10": dict(_GA3C, checkpt_dir="IROS18", checkpt_name="network_01900000",
+                          sensor_args={"agent_sorting_method": "closest_last", "max_num_other_agents_observed": 19}),
+    "GA3C-CADRL-4-LSTM": dict(_GA3C, checkpt_dir="run-20190727_015942-jzuhlntn", checkpt_name="network_01490000"),
+    "GA3C-CADRL-10-LSTM": dict(_GA3C, checkpt_dir="run-20190727_192048-qedrf08y", checkpt_name="network_01900000"),
+    "RVO": {"policy": "RVO", "sensors": ["other_agents_states"]},
+    "noncoop": {"policy": "noncoop", "sensors": ["other_agents_states"]},
+    "static": {"policy": "static", "sensors": ["other_agents_states"]},
+}

@@ -76,3 +76,13 @@ class Laser4(_Eval):
 
 class Example(_Eval):          # the reference's Example(EvaluateConfig): up to 19 agents, 18 observed
     N_MAX = 19
+
+
+class FullTestSuite(_Eval):    # the reference's FullTestSuite: up to 19 others observed, a handful of cases per policy
+    N_MAX, K = 19, 19
+
+    def __init__(self):
+        _Eval.__init__(self)
+        self.NUM_TEST_CASES = 6
+        self.NUM_AGENTS_TO_TEST = [3, 4]
+        self.POLICIES_TO_TEST = ["RVO", "GA3C-CADRL-10"]

@@ -269,3 +269,31 @@ def test_default_reset_path_draws_random_scenarios():
     for _ in range(400):
         venv2.step(None)
     assert venv2.episode_stats()["episodes"] >= 16
+
+
+def test_full_test_suite_runs_every_case_as_one_batch():
+    """run_full_test_suite (reference experiments/src/run_full_test_suite.py): all cases of the suite in one batch, one
+    row per case with run_episode's schema; a case evaluated alone through env_utils.run_episode gives the same row"""
+    Config, tc, Env = envtools.fresh("FullTestSuite")
+    import importlib
+    suite = importlib.import_module("gym_collision_avoidance_amd.experiments.run_full_test_suite")
+    eu = importlib.import_module("gym_collision_avoidance_amd.experiments.env_utils")
+    df = suite.run_suite("RVO", 4, test_cases=range(24))
+    assert len(df) == 24 and set(df["outcome"]) <= {"all_at_goal", "collision", "stuck"}
+    assert df["all_at_goal"].mean() > 0.7
+    meta, eps = gu.load("rvo4_swap")          # case 0 of the 4-agent fixture was recorded from the reference
+    assert int(df.loc[0, "steps"]) == eps[0].T and df.loc[0, "outcome"] == "all_at_goal"
+    np.testing.assert_allclose(df.loc[0, "total_reward"], eps[0].rewards.sum(axis=0), atol=1e-4)
+    for c in (3, 17):
+        env = Env()
+        env.set_agents(tc.full_test_suite(4, c, policies="RVO"))
+        env.reset()
+        stats, _ = eu.run_episode(env)
+        row = df.loc[c]
+        assert stats["steps"] == row["steps"] and stats["outcome"] == row["outcome"]
+        np.testing.assert_allclose(stats["time_to_goal"], row["time_to_goal"], atol=1e-9)
+        np.testing.assert_allclose(stats["total_reward"], row["total_reward"], atol=1e-5)
+    ga = suite.run_suite("GA3C-CADRL-10", 3, test_cases=range(12))
+    assert len(ga) == 12 and ga["all_at_goal"].mean() > 0.7
+    out = suite.main()
+    assert len(out) == 2 * 2 * 6
