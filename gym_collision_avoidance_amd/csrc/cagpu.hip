@@ -1161,7 +1161,7 @@ int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
 template <int NT, bool STAGE>
 int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
   if constexpr (NT <= 256) {  // the 512-thread geometry exists for large N only
-    if (STAGE && k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
+    if (k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
       return launch_main3<NT, STAGE, 10>(k, total, st);  // N and the tile size compiled in
   }
   return launch_main3<NT, STAGE, 0>(k, total, st);
@@ -1175,7 +1175,20 @@ int launch_main(const KArgs& k, hipStream_t st) {
   size_t un_sense = lds_sense_bytes(N, W, 1, tti);
   bool stage = true;
   size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
-  if (total > 64 * 1024) {  // keep >= 2 workgroups per CU when possible: give up the staging area first
+  // Staging the tile's observation block in LDS (one coalesced copy-out) wins while every workgroup of the launch is
+  // resident at once; for larger batches the smaller footprint without it (5 instead of 3 workgroups per CU at
+  // N = 10) hides more latency: 145 vs 167 us at 32768 envs, 32.9 vs 30.7 us at 4096 (profiles/r01_kernel_geometry.md).
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const long wgs = (static_cast<long>(k.p.num_envs) + k.tile_envs - 1) / k.tile_envs;
+  const long resident_staged = static_cast<long>((160 * 1024) / total) * n_cu;
+  const bool crowded = wgs > resident_staged && !std::getenv("CAGPU_STAGE");
+  if (total > 64 * 1024 || crowded || std::getenv("CAGPU_NOSTAGE")) {  // give up the staging area
     un_sense = lds_sense_bytes(N, W, 0, tti);
     stage = false;
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
