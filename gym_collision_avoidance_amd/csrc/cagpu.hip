@@ -1194,6 +1194,18 @@ int launch_main(const KArgs& k, hipStream_t st) {
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
+  if (crowded && k.mode == MODE_STEP && k.n_steps > 1) {
+    // the n-step kernel keeps ~215 VGPRs alive around its loop (2 waves / SIMD): once the launch no longer fits the
+    // chip at once, n launches of the lean single-step kernel are faster (136 vs 158 us / step at 32768 envs) and give
+    // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps)
+    KArgs k1 = k;
+    k1.n_steps = 1;
+    for (int i = 0; i < k.n_steps; ++i) {
+      const int rc = stage ? launch_main2<256, true>(k1, total, st) : launch_main2<256, false>(k1, total, st);
+      if (rc) return rc;
+    }
+    return CA_OK;
+  }
   return stage ? launch_main2<NT, true>(k, total, st) : launch_main2<NT, false>(k, total, st);
 }
 
