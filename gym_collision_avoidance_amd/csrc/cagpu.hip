@@ -1133,10 +1133,17 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
 
 template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64>
 int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
-  if (total > 48 * 1024) {
+  // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
+  static thread_local size_t lds_limit[16] = {0};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  size_t& lds_limit_set = lds_limit[dev_id & 15];
+  if (lds_limit_set == 0) lds_limit_set = 48 * 1024;
+  if (total > lds_limit_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, RW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    lds_limit_set = total;
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
@@ -1384,9 +1391,16 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   k.W = 6 + 7 * p->max_obs;
   k.net = *net; k.ext = ext_actions; k.logits = logits;
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ga3c::ga3c_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ga3c::LDS_BYTES));
-  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  static thread_local bool lds_raised[16] = {false};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  hipError_t e = hipSuccess;
+  if (!lds_raised[dev_id & 15]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ga3c::ga3c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(ga3c::LDS_BYTES));
+    if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    lds_raised[dev_id & 15] = true;
+  }
   const unsigned grid = static_cast<unsigned>((k.B + ga3c::TM - 1) / ga3c::TM);
   hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), ga3c::LDS_BYTES, static_cast<hipStream_t>(stream), k);
   e = hipGetLastError();
