@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--mode", choices=["step", "rollout"], default="step",
                     help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the rollout / two-stream extras (profiling runs: only the headline kernel is launched)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (lets a 1-GPU box exercise the N>1 code path with gloo)")
@@ -235,7 +237,7 @@ def main():
         }
         if a.workload != "rvo10":
             extra_workload(out, a, sim, core, E, N, K, dev, torch)
-        if world == 1 and a.mode == "step" and a.workload == "rvo10":
+        if world == 1 and a.mode == "step" and a.workload == "rvo10" and not a.no_extras:
             # extra: the same K steps fused into ONE cagpu_rollout launch (env_utils.run_episode's loop on the device)
             torch.cuda.synchronize(dev)
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -248,7 +250,7 @@ def main():
                               "ms_per_step": rms / a.steps, "launches": 1,
                               "note": "same workload, %d steps in one launch (state stays in registers/LDS between "
                                       "steps; observations, rewards and done flags are still written every step)" % a.steps}
-        if world == 1 and a.mode == "step" and a.workload == "rvo10" and E % 2 == 0:
+        if world == 1 and a.mode == "step" and a.workload == "rvo10" and E % 2 == 0 and not a.no_extras:
             # extra: the same batch as two half-batches on two HIP streams (envs are independent): the tail of one
             # launch -- a launch ends with its slowest workgroup -- overlaps with the body of the other
             halves, streams = [], [torch.cuda.Stream(device=dev) for _ in range(2)]

@@ -22,10 +22,10 @@ for n in ("rvo10", "ga3c20", "crowd50"):
 PY
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_*
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --no-cpu-baseline > $O/prof_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline > $O/prof_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline > $O/prof_write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/prof_sq -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline > $O/prof_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --no-cpu-baseline --no-extras > $O/prof_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline --no-extras > $O/prof_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline --no-extras > $O/prof_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/prof_sq -- python $R/bench.py --steps 300 --warmup 1500 --no-cpu-baseline --no-extras > $O/prof_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ga3c -- python $R/bench.py --workload ga3c20 --steps 100 --warmup 10 > $O/prof_ga3c.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_crowd -- python $R/bench.py --workload crowd50_laser --steps 50 --warmup 5 > $O/prof_crowd.log 2>&1
 cd $R
