@@ -44,6 +44,9 @@ SCENARIOS = {
     "clip6_rvo": dict(cfg="Clip6", kind="fixture", n=6, cases=[0, 1], policy="RVO", max_steps=400),
     # time_to_impact ordering (util.py:23-127) with K < N-1
     "tti6_rvo": dict(cfg="Tti6", kind="fixture", n=6, cases=[2, 3], policy="RVO", max_steps=400),
+    # every Config constant of the path off its default: finite SENSING_HORIZON (sensor + rvo2 neighborDist), wiggle
+    # and time-step rewards, thresholds, DT, RVO horizon / collaboration
+    "odd6_rvo": dict(cfg="Odd6", kind="fixture", n=6, cases=[4, 5, 6], policy="RVO", max_steps=400),
     # static map with obstacles + LaserScanSensor + wall collisions (Map.py, LaserScanSensor.py, env.py:494-506)
     "laser4": dict(cfg="Laser4", kind="laser", max_steps=90),
     # K > N-1, mixed policies / dynamics, a head-on collision, a static agent, an externally driven learner
@@ -171,7 +174,10 @@ def worker(name):
                 K=Config.MAX_NUM_OTHER_AGENTS_OBSERVED, n_max=Config.MAX_NUM_AGENTS_IN_ENVIRONMENT,
                 sort=Config.AGENT_SORTING_METHOD, evaluate=bool(Config.EVALUATE_MODE),
                 getting_close=Config.GETTING_CLOSE_RANGE, rvo_horizon=Config.RVO_TIME_HORIZON,
-                rvo_collab=Config.RVO_COLLAB_COEFF, states=list(Config.STATES_IN_OBS))
+                rvo_collab=Config.RVO_COLLAB_COEFF, states=list(Config.STATES_IN_OBS),
+                sensing_horizon=float(Config.SENSING_HORIZON), reward_at_goal=Config.REWARD_AT_GOAL,
+                reward_collision=Config.REWARD_COLLISION_WITH_AGENT, reward_time_step=Config.REWARD_TIME_STEP,
+                reward_wiggly=Config.REWARD_WIGGLY_BEHAVIOR, wiggly_threshold=float(Config.WIGGLY_BEHAVIOR_THRESHOLD))
     if sc["kind"] == "fixture":
         for c in sc["cases"]:
             agents = tc.get_testcase_from_fixture(sc["n"], c, sc["policy"]) if hasattr(tc, "get_testcase_from_fixture") \

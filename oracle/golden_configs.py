@@ -61,6 +61,26 @@ class Pad5(_Eval):          # K > N-1 (zero padding), 5 agents in a 8-slot env
     K = 7
 
 
+class Odd6(_Eval):          # every constant the hot path reads moved off its default (finite sensing horizon included)
+    N_MAX = 6
+    K = 4
+
+    def __init__(self):
+        _Eval.__init__(self)
+        self.DT = 0.2
+        self.MAX_TIME_RATIO = 3.0
+        self.SENSING_HORIZON = 4.0
+        self.NEAR_GOAL_THRESHOLD = 0.35
+        self.GETTING_CLOSE_RANGE = 0.45
+        self.REWARD_AT_GOAL = 1.5
+        self.REWARD_COLLISION_WITH_AGENT = -0.4
+        self.REWARD_TIME_STEP = -0.01
+        self.REWARD_WIGGLY_BEHAVIOR = -0.02
+        self.WIGGLY_BEHAVIOR_THRESHOLD = 0.15
+        self.RVO_TIME_HORIZON = 3.0
+        self.RVO_COLLAB_COEFF = 0.35
+
+
 class Train5(Config):       # training-mode rules: DT=0.2, MAX_TIME_RATIO=2, game over when learners done
     def __init__(self):
         self.MAX_NUM_AGENTS_IN_ENVIRONMENT = 5

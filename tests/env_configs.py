@@ -86,3 +86,22 @@ class FullTestSuite(_Eval):    # the reference's FullTestSuite: up to 19 others 
         self.NUM_TEST_CASES = 6
         self.NUM_AGENTS_TO_TEST = [3, 4]
         self.POLICIES_TO_TEST = ["RVO", "GA3C-CADRL-10"]
+
+
+class Odd6(_Eval):             # mirrors oracle/golden_configs.py:Odd6 (every constant of the path off its default)
+    N_MAX, K = 6, 4
+
+    def __init__(self):
+        _Eval.__init__(self)
+        self.DT = 0.2
+        self.MAX_TIME_RATIO = 3.0
+        self.SENSING_HORIZON = 4.0
+        self.NEAR_GOAL_THRESHOLD = 0.35
+        self.GETTING_CLOSE_RANGE = 0.45
+        self.REWARD_AT_GOAL = 1.5
+        self.REWARD_COLLISION_WITH_AGENT = -0.4
+        self.REWARD_TIME_STEP = -0.01
+        self.REWARD_WIGGLY_BEHAVIOR = -0.02
+        self.WIGGLY_BEHAVIOR_THRESHOLD = 0.15
+        self.RVO_TIME_HORIZON = 3.0
+        self.RVO_COLLAB_COEFF = 0.35

@@ -11,7 +11,7 @@ DATA = os.path.join(os.path.dirname(GOLD), "..", "gym_collision_avoidance_amd", 
 # columns of the recorded per-agent state (oracle/gen_golden.py:_snapshot)
 COLS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
         "time_remaining", "t", "slt", "act0", "act1", "step_num")
-SCENARIOS = ("rvo10", "rvo4_swap", "rvo3", "noncoop10", "clip6_rvo", "tti6_rvo", "mixed5", "train5")
+SCENARIOS = ("rvo10", "rvo4_swap", "rvo3", "noncoop10", "clip6_rvo", "tti6_rvo", "odd6_rvo", "mixed5", "train5")
 
 
 class Episode(object):
@@ -46,3 +46,20 @@ def load(name):
 
 def fixtures(n):
     return np.load(os.path.join(DATA, "test_cases.npz"))["n%d" % n]
+
+
+def apply_constants(meta, *params):
+    """Copy the Config constants recorded with a scenario into CaParams / OrcParams objects (same field names);
+    scenarios recorded before these keys existed ran with the defaults the parameter builders already use."""
+    names = {"near_goal": "near_goal_threshold", "getting_close": "getting_close_range",
+             "sensing_horizon": "sensing_horizon", "reward_at_goal": "reward_at_goal",
+             "reward_collision": "reward_collision", "reward_time_step": "reward_time_step",
+             "reward_wiggly": "reward_wiggly", "wiggly_threshold": "wiggly_threshold",
+             "rvo_horizon": "rvo_time_horizon", "rvo_collab": "rvo_collab_coeff"}
+    for p in params:
+        for k, field in names.items():
+            if k in meta:
+                setattr(p, field, float(meta[k]))
+        # collision_avoidance_env.py:589-599: clip bounds = min / max of the possible reward values
+        vals = [p.reward_at_goal, p.reward_collision, p.reward_time_step, p.reward_collision, p.reward_wiggly]
+        p.reward_min, p.reward_max = min(vals), max(vals)

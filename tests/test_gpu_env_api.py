@@ -11,7 +11,7 @@ from tests import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 
-CFG = {"rvo10": "Bench10", "rvo4_swap": "Swap4", "rvo3": "Small3", "noncoop10": "Bench10", "clip6_rvo": "Clip6", "tti6_rvo": "Tti6",
+CFG = {"rvo10": "Bench10", "rvo4_swap": "Swap4", "rvo3": "Small3", "noncoop10": "Bench10", "clip6_rvo": "Clip6", "tti6_rvo": "Tti6", "odd6_rvo": "Odd6",
        "mixed5": "Pad5", "train5": "Train5"}
 POL = {0: "RVO", 1: "noncoop", 2: "static", 3: "external", 4: "learning"}
 DYN = {0: "unicycle", 1: "unicycle_max_turn_rate", 2: "external"}

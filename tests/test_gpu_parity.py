@@ -84,6 +84,7 @@ def _golden_sim(meta, ep):
     over = nat.OVER_ALL_DONE if meta["evaluate"] else nat.OVER_LEARNING_DONE
     p = core.make_params(1, ep.N, max_obs=meta["K"], dt=meta["dt"], max_time_ratio=meta["max_time_ratio"],
                          sort_mode=SORT[meta["sort"]], game_over_mode=over, rvo_max_neighbors=meta["n_max"])
+    gu.apply_constants(meta, p)
     g = core.BatchedSim(p)
     g.set_plugins(ep.policy[None], ep.dynamics[None])
     return g

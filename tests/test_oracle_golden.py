@@ -27,6 +27,7 @@ def make_oracle(meta, ep):
     over = orc.OVER_ALL_DONE if meta["evaluate"] else orc.OVER_LEARNING_DONE
     p = orc.default_params(1, ep.N, max_obs=meta["K"], dt=meta["dt"], max_time_ratio=meta["max_time_ratio"],
                            sort_mode=SORT[meta["sort"]], game_over_mode=over, rvo_max_neighbors=meta["n_max"])
+    gu.apply_constants(meta, p)
     o = orc.Oracle(p)
     o.s["policy"][:] = ep.policy
     o.s["dynamics"][:] = ep.dynamics
