@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "csrc", "cagpu.hip")
 OUT = os.path.join(HERE, "libcagpu.so")
 # -ffp-contract=off: a fused multiply-add inside `dx*dx + dy*dy <= r*r` would change discrete events
 # (collision / at-goal masks) relative to the reference; see DESIGN.md "Numerics".
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-mllvm", "-disable-machine-licm",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared",
          "-I" + os.path.join(REPO, "include")]
 

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
   const int K = p.max_obs, W = 6 + 7 * K;
   const float inv_n = 1.0f / static_cast<float>(N);
-  const int tile_envs = (NC && !MULTI) ? ROW / (NC ? NC : 1) : k.tile_envs;  // compile-time in the specialised kernel
+  const int tile_envs = NC ? ROW / (NC ? NC : 1) : k.tile_envs;  // compile-time in the specialised kernel
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
@@ -1244,10 +1244,10 @@ int launch_g16(const KArgs& k, hipStream_t st) {
   return CA_OK;
 }
 
-// Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md).
-//   single step (cagpu_step / reset / observe): the straight-line kernel needs ~90 VGPRs, so five 4-wave workgroups
-//     fit a CU and all 683 workgroups are co-resident: 256 threads -> 48 us, 128 -> 55, 384/512 -> 63.
-//   n-step rollout: the in-kernel step loop costs ~235 VGPRs (2 waves/SIMD): 128 threads -> 36.7 us/step, 256 -> 54.
+// Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
+// single-step kernel (30.7 us; 128 -> 39, 384 / 512 -> 40) and the n-step rollout kernel (22.2 us / step; 128 -> 28.8).
+// The rollout kernel only reaches that since the build disables machine LICM (build_native.py): hoisted loop invariants
+// had cost it 217 VGPRs (2 waves / SIMD: the 683 workgroups of 256 threads no longer fit at once) instead of 139.
 // CAGPU_NT overrides for experiments.
 int launch_any(const KArgs& k0, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1263,7 +1263,7 @@ int launch_any(const KArgs& k0, void* stream) {
     if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
     return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);
   }
-  int nt = (k.mode == MODE_STEP && k.n_steps > 1) ? 128 : 256;
+  int nt = 256;
   if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
   // N > 32: the tile is a single env whose N^2 pair items (and N wave-wide linear programs) keep 8 waves busy, and
   // its LDS footprint allows only one or two workgroups per CU anyway
