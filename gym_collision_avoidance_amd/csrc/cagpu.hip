@@ -1201,7 +1201,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
-  if (crowded && k.mode == MODE_STEP && k.n_steps > 1) {
+  if (crowded && k.mode == MODE_STEP && k.n_steps > 1 && !std::getenv("CAGPU_ROLLOUT_FUSED")) {
     // the n-step kernel keeps ~215 VGPRs alive around its loop (2 waves / SIMD): once the launch no longer fits the
     // chip at once, n launches of the lean single-step kernel are faster (136 vs 158 us / step at 32768 envs) and give
     // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps)
