@@ -424,6 +424,30 @@ class CollisionAvoidanceEnv(Env):
         return None if self._sim is None else self._sim.scan
 
     # ------------------------------------------------------------------ batched extras
+    def rollout(self, n_steps):
+        """n_steps x `step(None)` in ONE launch (`cagpu_rollout`): the device-side form of env_utils.run_episode's
+        `while not terminated: env.step(None)` loop for scenes whose policies are all internal.  Returns the last step's
+        (obs, rewards, game_over, False, info); per-episode results accumulate in episode_stats() through the on-device
+        auto-reset.  About 1.4x the throughput of n step() calls at 4096 x 10: a fused rollout never waits for the
+        slowest workgroup of a step."""
+        if self._sim is None:
+            raise RuntimeError("call reset() before rollout()")
+        if any(a.policy.is_external for a in self.agents) or self._host_policies:
+            raise ValueError("rollout() needs every policy to be internal (no external actions between the steps)")
+        sim = self._sim
+        sim.p.dt = self.dt_nominal
+        self.episode_step_number += int(n_steps)
+        sim.rollout(int(n_steps))
+        self._snap, self._obs_np, self._scan_np = None, None, None
+        if Config.USE_STATIC_MAP:
+            sim.laserscan()
+        info = {"which_agents_done": sim.done.bool() if self.num_envs > 1 else
+                {a.id: bool(d) for a, d in zip(self.agents, sim.done[0].cpu().numpy())},
+                "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
+        if self.num_envs > 1:
+            return sim.obs, sim.rewards, sim.game_over.bool(), False, info
+        return self._get_obs(), sim.rewards[0].double().cpu().numpy(), bool(sim.game_over[0].item()), False, info
+
     def episode_stats(self):
         """{name: value} of the episode counters accumulated on the device (core.STAT_NAMES), this shard only;
         reduce across GPUs with sharding.reduce_episode_stats."""

@@ -297,3 +297,24 @@ def test_full_test_suite_runs_every_case_as_one_batch():
     assert len(ga) == 12 and ga["all_at_goal"].mean() > 0.7
     out = suite.main()
     assert len(out) == 2 * 2 * 6
+
+
+def test_env_rollout_matches_repeated_steps():
+    """env.rollout(n) == n x env.step(None) (same launch sequence on the device), refused when a policy is external"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    a, b = Env(num_envs=64), Env(num_envs=64)
+    for e in (a, b):
+        e.set_fixture_suite(10, "RVO")
+        e.reset()
+    for _ in range(60):
+        a.step(None)
+    obs, rew, over, _, info = b.rollout(60)
+    import torch
+    assert torch.equal(a._sim.obs, obs) and torch.equal(a._sim.rewards, rew)
+    assert a.episode_stats() == b.episode_stats() and b.episode_step_number == 60
+    Config, tc, Env = envtools.fresh("Example")
+    env = Env()
+    env.set_agents(tc.get_testcase_two_agents(policies=("learning", "RVO")))
+    env.reset()
+    with pytest.raises(ValueError):
+        env.rollout(5)
