@@ -355,10 +355,10 @@ __host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static
 __host__ __device__ inline size_t lds_orca_bytes(int N, int row = ROW) {
   return static_cast<size_t>(row) * N * 4 + static_cast<size_t>(row) * (N > 1 ? N - 1 : 1) * 16;
 }
-// union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] i32,
+// union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] u8,
 // obs staging [ROW*W] f32
 __host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti, int row = ROW) {
-  return static_cast<size_t>(row) * N * ((tti ? 5 : 4) * 8 + 4) + (stage ? align16(static_cast<size_t>(row) * W * 4) : 0);
+  return align16(static_cast<size_t>(row) * N * ((tti ? 5 : 4) * 8 + 1)) + (stage ? align16(static_cast<size_t>(row) * W * 4) : 0);
 }
 
 struct Lane {  // per-lane registers of one agent (wave 0)
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   double* gmat = d2mat + static_cast<size_t>(N) * ROW;   // [N][ROW] centre distance - combined radius
   const int has_tti = (p.sort_mode == CA_SORT_TIME_TO_IMPACT) ? 1 : 0;
   double* tmat = gmat + static_cast<size_t>(N) * ROW;    // [N][ROW] time to impact (time_to_impact sorting only)
-  int* rmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(has_tti ? N : 0) * ROW);  // [N][ROW] rank
-  float* sh_obs = reinterpret_cast<float*>(un + static_cast<size_t>(ROW) * N * ((has_tti ? 5 : 4) * 8 + 4));
+  uint8_t* rmat = reinterpret_cast<uint8_t*>(tmat + static_cast<size_t>(has_tti ? N : 0) * ROW);  // [N][ROW] rank (<= N <= 64)
+  float* sh_obs = reinterpret_cast<float*>(un + align16(static_cast<size_t>(ROW) * N * ((has_tti ? 5 : 4) * 8 + 1)));
 
   // ---- load my agent
   Lane r;
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           }
         const bool kept = (j != aa) && (kj < INFINITY) && (rank < keep);
         if (p.sort_mode == CA_SORT_CLOSEST_LAST) {
-          rmat[j * ROW + ag] = kept ? rank : N;
+          rmat[j * ROW + ag] = static_cast<uint8_t>(kept ? rank : N);
           continue;
         }
         if (!kept) continue;
