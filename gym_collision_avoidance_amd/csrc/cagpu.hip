@@ -58,6 +58,7 @@ struct KArgs {
   CaMap map;  // static obstacles for wall collisions (static_bits == NULL: none)
   int32_t n_steps, mode, stage_obs;
   int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
+  int32_t col_stride; // columns of the per-(agent, slot) LDS tiles: ROW, or N for single-env tiles (N > 32)
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -334,6 +335,7 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 // Everything the phases exchange lives in LDS; per-(agent, slot) arrays are [slot][ROW] columns so that a phase that
 // walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
 constexpr int ROW = 64;
+constexpr int KEY_NONE = 2147483647;  // sort key of a pair that is not sensed (self, beyond the sensing horizon)
 #ifdef CAGPU_ABLATE
 #define AB(bit) (k.ablate & (bit))
 __device__ unsigned long long g_prof[16];
@@ -352,13 +354,13 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 __host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static_cast<size_t>(row) * (10 * 8 + 10 * 4 + 4 * 4); }
 // union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
 // the registers of the solving group)
-__host__ __device__ inline size_t lds_orca_bytes(int N, int row = ROW) {
-  return static_cast<size_t>(row) * N * 4 + static_cast<size_t>(row) * (N > 1 ? N - 1 : 1) * 16;
+__host__ __device__ inline size_t lds_orca_bytes(int N, int cs = ROW) {
+  return align16(static_cast<size_t>(cs) * N * 4) + static_cast<size_t>(cs) * (N > 1 ? N - 1 : 1) * 16;
 }
-// union, sensor view: key / p_orth / dist_2_other / gap / time-to-impact [N][ROW] f64, rank [N][ROW] u8,
+// union, sensor view: p_orth / gap / time-to-impact [N][CS] f64, key i32, dist_2_other f32, rank u8,
 // obs staging [ROW*W] f32
-__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti, int row = ROW) {
-  return align16(static_cast<size_t>(row) * N * ((tti ? 5 : 4) * 8 + 1)) + (stage ? align16(static_cast<size_t>(row) * W * 4) : 0);
+__host__ __device__ inline size_t lds_sense_bytes(int N, int W, int stage, int tti, int cs = ROW, int row = ROW) {
+  return align16(static_cast<size_t>(cs) * N * ((tti ? 3 : 2) * 8 + 9)) + (stage ? align16(static_cast<size_t>(row) * W * 4) : 0);
 }
 
 struct Lane {  // per-lane registers of one agent (wave 0)
@@ -436,18 +438,23 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   float* sh_fprx = sh_fms + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
   unsigned char* un = smem + lds_fixed_bytes(ROW);
+  // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
+  // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
+  const int CS = NC ? ROW : k.col_stride;
   // ORCA view of the union
-  float* dmat = reinterpret_cast<float*>(un);                                   // [N][ROW]
-  float4* Lmat = reinterpret_cast<float4*>(un + static_cast<size_t>(ROW) * N * 4);  // [N-1][ROW]
+  float* dmat = reinterpret_cast<float*>(un);                                   // [N][CS]
+  float4* Lmat = reinterpret_cast<float4*>(un + align16(static_cast<size_t>(CS) * N * 4));  // [N-1][CS]
   // sensor view of the union
-  double* kmat = reinterpret_cast<double*>(un);          // [N][ROW] sort key = rint(100 * dist_2_other)
-  double* omat = kmat + static_cast<size_t>(N) * ROW;    // [N][ROW] p_orth
-  double* d2mat = omat + static_cast<size_t>(N) * ROW;   // [N][ROW] dist_2_other
-  double* gmat = d2mat + static_cast<size_t>(N) * ROW;   // [N][ROW] centre distance - combined radius
+  // p_orth and the collision gap stay float64 (they decide order / collisions); the sort bucket rint(100 d) is an
+  // integer (int32, KEY_NONE = not sensed) and dist_2_other is only emitted as float32: 25 B per pair instead of 33.
+  double* omat = reinterpret_cast<double*>(un);          // [N][CS] p_orth
+  double* gmat = omat + static_cast<size_t>(N) * CS;     // [N][CS] centre distance - combined radius
   const int has_tti = (p.sort_mode == CA_SORT_TIME_TO_IMPACT) ? 1 : 0;
-  double* tmat = gmat + static_cast<size_t>(N) * ROW;    // [N][ROW] time to impact (time_to_impact sorting only)
-  uint8_t* rmat = reinterpret_cast<uint8_t*>(tmat + static_cast<size_t>(has_tti ? N : 0) * ROW);  // [N][ROW] rank (<= N <= 64)
-  float* sh_obs = reinterpret_cast<float*>(un + align16(static_cast<size_t>(ROW) * N * ((has_tti ? 5 : 4) * 8 + 1)));
+  double* tmat = gmat + static_cast<size_t>(N) * CS;     // [N][CS] time to impact (time_to_impact sorting only)
+  int* kmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(has_tti ? N : 0) * CS);  // [N][CS] sort key
+  float* d2mat = reinterpret_cast<float*>(kmat + static_cast<size_t>(N) * CS);           // [N][CS] dist_2_other
+  uint8_t* rmat = reinterpret_cast<uint8_t*>(d2mat + static_cast<size_t>(N) * CS);       // [N][CS] rank (<= N <= 64)
+  float* sh_obs = reinterpret_cast<float*>(un + align16(static_cast<size_t>(CS) * N * ((has_tti ? 3 : 2) * 8 + 9)));
 
   // ---- load my agent
   Lane r;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             d2 = dotf(d, d);
             if (!(d2 < range_sq)) d2 = INFINITY;
           }
-          dmat[j * ROW + ag] = d2;
+          dmat[j * CS + ag] = d2;
         }
         __syncthreads();
         // ================= P2: neighbour rank (ascending distSq, ties by index) + ORCA half-plane
@@ -557,10 +564,10 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           const int j = w - ag * N;
           if (!sh_q[ag]) continue;
           const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
-          const float dj = dmat[j * ROW + ag];
+          const float dj = dmat[j * CS + ag];
           int rank = 0, cnt = 0;
           for (int q = 0; q < N; ++q) {
-            const float dq = dmat[q * ROW + ag];
+            const float dq = dmat[q * CS + ag];
             rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
             cnt += static_cast<int>(dq < INFINITY);
           }
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           if (j == aa) {
             sh_nb[ag] = n;
           } else if (dj < INFINITY && rank < n) {
-            Lmat[rank * ROW + ag] = half_plane(f2(sh_fpx[ag], sh_fpy[ag]), f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
+            Lmat[rank * CS + ag] = half_plane(f2(sh_fpx[ag], sh_fpy[ag]), f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
                                                f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
                                                sh_frad[eb + j], collab, inv_h, ts);
           }
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
               if (!sh_q[agf]) continue;
               const int nf = sh_nb[agf];
               const bool valid = jl < nf;
-              const float4 ln = Lmat[(valid ? jl : 0) * ROW + agf];
+              const float4 ln = Lmat[(valid ? jl : 0) * CS + agf];
               const F2 P = f2(ln.x, ln.y), D = f2(ln.z, ln.w);
               const float ms = sh_fms[agf];
               F2 v;
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             for (int q3 = (g % GPW) * (NT / 64) + (g / GPW); q3 < n3; q3 += GROUPS) {
               const int ent = sh_sense[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
               const int nf = sh_nb[agf];
-              const float4 ln = Lmat[((jl < nf) ? jl : 0) * ROW + agf];
+              const float4 ln = Lmat[((jl < nf) ? jl : 0) * CS + agf];
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
               lp3_group<GS>(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
               if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
@@ -750,7 +757,8 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         const int j = w - ag * N;
         if (!sh_sense[ag]) continue;
         const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
-        double key = INFINITY, po = 0.0, d2o = 0.0, gap = INFINITY;
+        int key = KEY_NONE;
+        double po = 0.0, d2o = 0.0, gap = INFINITY;
         if (j != aa) {
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag];
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
@@ -759,17 +767,18 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           gap = d - (hr + orad);
           if (!(d > p.sensing_horizon)) {
             d2o = d - hr - orad;
-            key = rint(d2o * 100.0);  // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100
+            // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100 (an integer: exact as int32)
+            key = static_cast<int>(fmin(fmax(rint(d2o * 100.0), -2.0e9), 2.0e9));
             po = rx * (-sh_pry[ag]) + ry * sh_prx[ag];
             if (p.sort_mode == CA_SORT_TIME_TO_IMPACT)  // sensor :96-104
-              tmat[j * ROW + ag] = time_to_impact(hx, hy, ox, oy, sh_vx[ag], sh_vy[ag], sh_vx[eb + j], sh_vy[eb + j],
+              tmat[j * CS + ag] = time_to_impact(hx, hy, ox, oy, sh_vx[ag], sh_vy[ag], sh_vx[eb + j], sh_vy[eb + j],
                                                   hr + orad);
           }
         }
-        kmat[j * ROW + ag] = key;
-        omat[j * ROW + ag] = po;
-        d2mat[j * ROW + ag] = d2o;
-        gmat[j * ROW + ag] = gap;
+        kmat[j * CS + ag] = key;
+        omat[j * CS + ag] = po;
+        d2mat[j * CS + ag] = static_cast<float>(d2o);
+        gmat[j * CS + ag] = gap;
       }
       __syncthreads();
 
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         if (k.mode == MODE_STEP && pass == 0) {
           double nearest = INFINITY;
           for (int j = 0; j < N; ++j) {
-            const double g = gmat[j * ROW + lane];
+            const double g = gmat[j * CS + lane];
             nearest = (g < nearest) ? g : nearest;
           }
           const bool coll = nearest <= 0.0;  // some d <= r_i + r_j  <=>  min(d - (r_i + r_j)) <= 0
@@ -826,15 +835,17 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         const int j = w - ag * N;
         if (!sh_sense[ag]) continue;
         const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
-        const double kj = kmat[j * ROW + ag], oj = omat[j * ROW + ag];
+        const int kj = kmat[j * CS + ag];
+        const double oj = omat[j * CS + ag];
         int rank = 0, cnt = 0;
         if (p.sort_mode == CA_SORT_TIME_TO_IMPACT) {  // key (-tti, -dist, p_orth), sensor :36-38
-          const bool vj = kj < INFINITY;
-          const double tj = vj ? tmat[j * ROW + ag] : 0.0;
+          const bool vj = kj != KEY_NONE;
+          const double tj = vj ? tmat[j * CS + ag] : 0.0;
           for (int q = 0; q < N; ++q) {
-            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
-            const bool vq = kq < INFINITY;
-            const double tq = vq ? tmat[q * ROW + ag] : 0.0;
+            const int kq = kmat[q * CS + ag];
+            const double oq = omat[q * CS + ag];
+            const bool vq = kq != KEY_NONE;
+            const double tq = vq ? tmat[q * CS + ag] : 0.0;
             const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j));
             const int lk = static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo);
             const int before = static_cast<int>(tq > tj) | (static_cast<int>(tq == tj) & lk);
@@ -847,12 +858,13 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           // with one wait for all of them (the short-circuit form compiled to a chain of dependent LDS round trips
           // and ~10 taken branches per item)
           for (int q = 0; q < N; ++q) {
-            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+            const int kq = kmat[q * CS + ag];
+            const double oq = omat[q * CS + ag];
             const int before = static_cast<int>(kq < kj) |
                                (static_cast<int>(kq == kj) &
                                 (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j))));
             rank += before;
-            cnt += static_cast<int>(kq < INFINITY);
+            cnt += static_cast<int>(kq != KEY_NONE);
           }
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
@@ -863,9 +875,9 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
             float* z = row + 6 + 7 * sl;
             z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = z[6] = 0.f;
           }
-        const bool kept = (j != aa) && (kj < INFINITY) && (rank < keep);
+        const bool kept = (j != aa) && (kj != KEY_NONE) && (rank < keep);
         if (p.sort_mode == CA_SORT_CLOSEST_LAST) {
-          rmat[j * ROW + ag] = static_cast<uint8_t>(kept ? rank : N);
+          rmat[j * CS + ag] = static_cast<uint8_t>(kept ? rank : N);
           continue;
         }
         if (!kept) continue;
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
         o7[3] = static_cast<float>(ovx * (-pry) + ovy * prx);
         o7[4] = static_cast<float>(orad);
         o7[5] = static_cast<float>(hr + orad);
-        o7[6] = static_cast<float>(d2mat[j * ROW + ag]);
+        o7[6] = d2mat[j * CS + ag];
       }
       if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
         __syncthreads();
@@ -888,14 +900,16 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
           const int j = w - ag * N;
           if (!sh_sense[ag]) continue;
-          const int rank = rmat[j * ROW + ag];
+          const int rank = rmat[j * CS + ag];
           if (rank >= N) continue;
           const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N;
-          const double kj = kmat[j * ROW + ag], oj = omat[j * ROW + ag];
+          const int kj = kmat[j * CS + ag];
+          const double oj = omat[j * CS + ag];
           int r2 = 0;
           for (int q = 0; q < N; ++q) {
-            const int rq = rmat[q * ROW + ag];
-            const double kq = kmat[q * ROW + ag], oq = omat[q * ROW + ag];
+            const int rq = rmat[q * CS + ag];
+            const int kq = kmat[q * CS + ag];
+            const double oq = omat[q * CS + ag];
             const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(rq < rank));
             r2 += static_cast<int>(rq < N) & (static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo));
           }
@@ -911,7 +925,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
           o7[3] = static_cast<float>(ovx * (-pry) + ovy * prx);
           o7[4] = static_cast<float>(orad);
           o7[5] = static_cast<float>(hr + orad);
-          o7[6] = static_cast<float>(d2mat[j * ROW + ag]);
+          o7[6] = d2mat[j * CS + ag];
         }
       }
       __syncthreads();
@@ -1177,9 +1191,10 @@ int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
 template <int NT>
 int launch_main(const KArgs& k, hipStream_t st) {
   const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
-  const size_t un_orca = lds_orca_bytes(N);
+  const int cs = k.col_stride;
+  const size_t un_orca = lds_orca_bytes(N, cs);
   const int tti = k.p.sort_mode == CA_SORT_TIME_TO_IMPACT ? 1 : 0;
-  size_t un_sense = lds_sense_bytes(N, W, 1, tti);
+  size_t un_sense = lds_sense_bytes(N, W, 1, tti, cs);
   bool stage = true;
   size_t total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   // Staging the tile's observation block in LDS (one coalesced copy-out) wins while every workgroup of the launch is
@@ -1196,7 +1211,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
   const long resident_staged = static_cast<long>((160 * 1024) / total) * n_cu;
   const bool crowded = wgs > resident_staged && !std::getenv("CAGPU_STAGE");
   if (total > 64 * 1024 || crowded || std::getenv("CAGPU_NOSTAGE")) {  // give up the staging area
-    un_sense = lds_sense_bytes(N, W, 0, tti);
+    un_sense = lds_sense_bytes(N, W, 0, tti, cs);
     stage = false;
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
@@ -1254,6 +1269,7 @@ int launch_any(const KArgs& k0, void* stream) {
   KArgs k = k0;
   const int N = k.p.num_agents;
   k.tile_envs = ROW / N;
+  k.col_stride = (N > 32) ? N : ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
   if (const char* e = std::getenv("CAGPU_TILE")) {  // experiments
     const int t = std::atoi(e);
     if (t >= 1 && t < k.tile_envs) k.tile_envs = t;
