@@ -231,7 +231,7 @@ def main():
                          "traffic": measured_traffic_bytes(E, N) if a.mode == "step" else None,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_rocprof_summary.md)",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "ca_kernel<256, true, 10, false, true, 64>", "avg_launch_us": kern_s * 1e6,
+                         "kernel": "ca_kernel<256, false, 10, false, true, 64, 4>", "avg_launch_us": kern_s * 1e6,
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
         }

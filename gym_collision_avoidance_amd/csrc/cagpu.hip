@@ -350,8 +350,8 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 #include "cagpu_scan.inc"
 #include "cagpu_ga3c.inc"
 
-// fixed: 10 f64 + 10 f32 + 4 u32 per agent slot
-__host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static_cast<size_t>(row) * (10 * 8 + 10 * 4 + 4 * 4); }
+// fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays)
+__host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4); }
 // union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
 // the registers of the solving group)
 __host__ __device__ inline size_t lds_orca_bytes(int N, int cs = ROW) {
@@ -387,7 +387,7 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64, int TE = 0>
 __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   constexpr int ROW = RW;  // agent slots of the tile (shadows the default): 64, or 32 for half-size tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
   const int K = p.max_obs, W = 6 + 7 * K;
   const float inv_n = 1.0f / static_cast<float>(N);
-  const int tile_envs = NC ? ROW / (NC ? NC : 1) : k.tile_envs;  // compile-time in the specialised kernel
+  const int tile_envs = TE ? TE : (NC ? ROW / (NC ? NC : 1) : k.tile_envs);  // compile-time in the specialised kernels
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
@@ -420,22 +420,22 @@ __global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
   double* sh_rad = sh_vy + ROW;
   double* sh_prx = sh_rad + ROW;  // ego frame ref_prll (ref_orth = (-pry, prx))
   double* sh_pry = sh_prx + ROW;
-  double* sh_r0 = sh_pry + ROW;   // episode-stat scratch
-  double* sh_r1 = sh_r0 + ROW;
-  double* sh_r2 = sh_r1 + ROW;
-  float* sh_fpx = reinterpret_cast<float*>(sh_r2 + ROW);
+  float* sh_fpx = reinterpret_cast<float*>(sh_pry + ROW);  // ORCA's float bodies (dead once the policy phase is over)
   float* sh_fpy = sh_fpx + ROW;
   float* sh_fvx = sh_fpy + ROW;
   float* sh_fvy = sh_fvx + ROW;
   float* sh_frad = sh_fvy + ROW;
-  uint32_t* sh_flag = reinterpret_cast<uint32_t*>(sh_frad + ROW);
+  float* sh_fms = sh_frad + ROW;                      // speed limit (float pref_speed)
+  double* sh_r0 = reinterpret_cast<double*>(sh_fpx);  // episode-stat scratch of A3 -> A4: aliases the six arrays above
+  double* sh_r1 = sh_r0 + ROW;
+  double* sh_r2 = sh_r1 + ROW;
+  uint32_t* sh_flag = reinterpret_cast<uint32_t*>(sh_fms + ROW);
   int* sh_q = reinterpret_cast<int*>(sh_flag + ROW);  // 1: this agent queries ORCA this step
   int* sh_nb = sh_q + ROW;                            // its neighbour count n
   int* sh_sense = sh_nb + ROW;                        // 1: (re)write this agent's observation in this pass
   float* sh_vrx = reinterpret_cast<float*>(sh_sense + ROW);  // ORCA velocity of each agent
   float* sh_vry = sh_vrx + ROW;
-  float* sh_fms = sh_vry + ROW;                       // its speed limit (float pref_speed)
-  float* sh_fprx = sh_fms + ROW;                      // its preferred velocity (float)
+  float* sh_fprx = sh_vry + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
@@ -1145,7 +1145,7 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64, int TE = 0>
 int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
   static thread_local size_t lds_limit[16] = {0};
@@ -1154,36 +1154,38 @@ int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   size_t& lds_limit_set = lds_limit[dev_id & 15];
   if (lds_limit_set == 0) lds_limit_set = 48 * 1024;
   if (total > lds_limit_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, RW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, RW, TE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
     lds_limit_set = total;
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, RW>), dim3(grid), dim3(NT), total, st, k);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, RW, TE>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI>
+template <int NT, bool STAGE, int NC, bool MULTI, int TE = 0>
 int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
-  if (k.mode == MODE_STEP && k.table && k.reset_obs) return launch_main5<NT, STAGE, NC, MULTI, true>(k, total, st);
-  return launch_main5<NT, STAGE, NC, MULTI, false>(k, total, st);
+  if (k.mode == MODE_STEP && k.table && k.reset_obs) return launch_main5<NT, STAGE, NC, MULTI, true, 64, TE>(k, total, st);
+  return launch_main5<NT, STAGE, NC, MULTI, false, 64, TE>(k, total, st);
 }
 
-template <int NT, bool STAGE, int NC>
+template <int NT, bool STAGE, int NC, int TE = 0>
 int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
-  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_main4<NT, STAGE, NC, true>(k, total, st);
-  return launch_main4<NT, STAGE, NC, false>(k, total, st);
+  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_main4<NT, STAGE, NC, true, TE>(k, total, st);
+  return launch_main4<NT, STAGE, NC, false, TE>(k, total, st);
 }
 
 template <int NT, bool STAGE>
 int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
   if constexpr (NT <= 256) {  // the 512-thread geometry exists for large N only
-    if (k.p.num_agents == 10 && k.tile_envs == ROW / 10 && !std::getenv("CAGPU_NO_NC"))
-      return launch_main3<NT, STAGE, 10>(k, total, st);  // N and the tile size compiled in
+    if (k.p.num_agents == 10 && !std::getenv("CAGPU_NO_NC")) {  // N and the tile size compiled in
+      if (k.tile_envs == ROW / 10) return launch_main3<NT, STAGE, 10>(k, total, st);
+      if (k.tile_envs == 4) return launch_main3<NT, STAGE, 10, 4>(k, total, st);
+    }
   }
   return launch_main3<NT, STAGE, 0>(k, total, st);
 }
@@ -1208,7 +1210,10 @@ int launch_main(const KArgs& k, hipStream_t st) {
     if (n_cu <= 0) n_cu = 256;
   }
   const long wgs = (static_cast<long>(k.p.num_envs) + k.tile_envs - 1) / k.tile_envs;
-  const long resident_staged = static_cast<long>((160 * 1024) / total) * n_cu;
+  // (a fourth staged workgroup per CU fits the LDS on paper at N = 10 but measured 44 us at 5120 envs against 35 us for
+  // the unstaged layout, so the staged layout is only kept up to three per CU)
+  const long per_cu = static_cast<long>((160 * 1024) / total);
+  const long resident_staged = (per_cu < 3 ? per_cu : 3) * n_cu;
   const bool crowded = wgs > resident_staged && !std::getenv("CAGPU_STAGE");
   if (total > 64 * 1024 || crowded || std::getenv("CAGPU_NOSTAGE")) {  // give up the staging area
     un_sense = lds_sense_bytes(N, W, 0, tti, cs);
@@ -1270,6 +1275,19 @@ int launch_any(const KArgs& k0, void* stream) {
   const int N = k.p.num_agents;
   k.tile_envs = ROW / N;
   k.col_stride = (N > 32) ? N : ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
+  // N = 10, one launch per step: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all
+  // co-resident, evenly spread): 27.3 vs 30.9 us at 4096 envs, 23.3 vs 27.6 at 2048; beyond that (and for the fused
+  // n-step kernel, whose 139 VGPRs allow 3 workgroups per CU) the 6-env tile wins (profiles/r01_kernel_geometry.md)
+  if (N == 10 && k.mode == MODE_STEP && k.n_steps == 1 && !std::getenv("CAGPU_TILE")) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    static thread_local int cu_cache[16] = {0};
+    if (hipGetDevice(&dev) == hipSuccess) {
+      if (!cu_cache[dev & 15] && hipGetDeviceProperties(&prop, dev) == hipSuccess) cu_cache[dev & 15] = prop.multiProcessorCount;
+      if (cu_cache[dev & 15] > 0) cus = cu_cache[dev & 15];
+    }
+    if ((static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * cus) k.tile_envs = 4;
+  }
   if (const char* e = std::getenv("CAGPU_TILE")) {  // experiments
     const int t = std::atoi(e);
     if (t >= 1 && t < k.tile_envs) k.tile_envs = t;
