@@ -388,7 +388,7 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
 }
 
 template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64, int TE = 0>
-__global__ __launch_bounds__(NT) void ca_kernel(const KArgs k) {
+__global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) {  // n-step: <= 128 VGPRs (4 waves / SIMD)
   constexpr int ROW = RW;  // agent slots of the tile (shadows the default): 64, or 32 for half-size tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
@@ -1221,10 +1221,12 @@ int launch_main(const KArgs& k, hipStream_t st) {
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
   }
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: num_agents too large for the 160 KiB LDS tile%s");
-  if (crowded && k.mode == MODE_STEP && k.n_steps > 1 && !std::getenv("CAGPU_ROLLOUT_FUSED")) {
-    // the n-step kernel keeps ~215 VGPRs alive around its loop (2 waves / SIMD): once the launch no longer fits the
-    // chip at once, n launches of the lean single-step kernel are faster (136 vs 158 us / step at 32768 envs) and give
-    // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps)
+  // The fused n-step kernel (<= 128 VGPRs: four 4-wave workgroups per CU) only pays while the whole launch is resident
+  // at once; otherwise n launches of the single-step kernel are faster (136 vs 158 us / step at 32768 envs) and give
+  // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps).
+  const long lds_cap = static_cast<long>((160 * 1024) / total);
+  const long fused_resident = (lds_cap < 4 ? lds_cap : 4) * n_cu;
+  if (k.mode == MODE_STEP && k.n_steps > 1 && wgs > fused_resident && !std::getenv("CAGPU_ROLLOUT_FUSED")) {
     KArgs k1 = k;
     k1.n_steps = 1;
     for (int i = 0; i < k.n_steps; ++i) {
@@ -1275,10 +1277,10 @@ int launch_any(const KArgs& k0, void* stream) {
   const int N = k.p.num_agents;
   k.tile_envs = ROW / N;
   k.col_stride = (N > 32) ? N : ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
-  // N = 10, one launch per step: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all
-  // co-resident, evenly spread): 27.3 vs 30.9 us at 4096 envs, 23.3 vs 27.6 at 2048; beyond that (and for the fused
-  // n-step kernel, whose 139 VGPRs allow 3 workgroups per CU) the 6-env tile wins (profiles/r01_kernel_geometry.md)
-  if (N == 10 && k.mode == MODE_STEP && k.n_steps == 1 && !std::getenv("CAGPU_TILE")) {
+  // N = 10: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all co-resident, evenly
+  // spread): 27.3 vs 30.9 us at 4096 envs, 23.3 vs 27.6 at 2048; beyond that the 6-env tile wins
+  // (profiles/r01_kernel_geometry.md)
+  if (N == 10 && k.mode == MODE_STEP && !std::getenv("CAGPU_TILE")) {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     static thread_local int cu_cache[16] = {0};
