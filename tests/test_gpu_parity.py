@@ -629,3 +629,29 @@ def test_fuzzed_config_constants_vs_oracle(seed):
         o.step()
         g.step()
         _compare(o, g, tol=2e-5 if np.isfinite(extra["wiggly_threshold"]) else TOL, what="seed %d step %d" % (seed, t))
+
+
+def test_auto_reset_without_precomputed_observations():
+    """CaAutoReset.reset_obs == NULL (a caller of the C ABI that did not precompute the reset observations): the kernel
+    re-runs the sensing phases for the envs that reset; outputs and state are bit-identical to the table path"""
+    nat, core, orc = _mods()
+    N, E = 10, 300
+    table = gu.fixtures(N)
+    sims = []
+    for with_obs in (True, False):
+        g = core.BatchedSim(core.make_params(E, N))
+        g.set_plugins(nat.POL_RVO)
+        g.set_fixture_table(table)
+        if not with_obs:
+            g._ar.reset_obs = None
+        g.reset_from_table()
+        sims.append(g)
+    for t in range(260):
+        for g in sims:
+            g.step()
+        if t % 20 == 19:
+            assert torch.equal(sims[0].obs, sims[1].obs), t
+    assert float(sims[0].episode_stats()[0]) > 100        # plenty of auto-resets happened
+    for n in F64 + ("flags", "step_num", "episode_step", "reset_count", "env_stats"):
+        assert torch.equal(sims[0].state[n], sims[1].state[n]), n
+    assert torch.equal(sims[0].rewards, sims[1].rewards) and torch.equal(sims[0].done, sims[1].done)
