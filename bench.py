@@ -34,7 +34,7 @@ GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
 def measured_traffic_bytes(envs, agents):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, profiles/), if they were
     taken at this geometry; bench.py itself does not run the profiler."""
-    f = os.path.join(REPO, "profiles", "r01_traffic.json")
+    f = os.path.join(REPO, "profiles", "r02_traffic.json")
     if os.path.exists(f):
         d = json.load(open(f))
         if d.get("envs") == envs and d.get("agents") == agents:
@@ -47,27 +47,55 @@ def algorithmic_bytes_per_agent_step(K):
     return 104 + 28 * K
 
 
-def cpu_baseline(n_agents, K, budget_s=12.0):
-    """The CPU oracle (oracle/ca_oracle.cpp, a single-threaded C++ restatement of the reference step: kind
-    'port') timed on this host on a bounded sample of the same workload."""
+def _port_leg(args):
+    """one process of the CPU port: E envs x n_agents stepped for ~budget_s seconds (module level: picklable)"""
+    n_agents, K, budget_s, rank = args
     from oracle import ca_oracle as orc
     table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % n_agents]
     E = 64
     o = orc.Oracle(orc.default_params(E, n_agents, max_obs=K))
     o.s["policy"][:] = orc.POL_RVO
-    o.reset(table[np.arange(E) % table.shape[0]])
+    o.reset(table[(np.arange(E) + 64 * rank) % table.shape[0]])
     t0 = time.perf_counter()
     o.rollout(table, 50)
     dt = time.perf_counter() - t0
-    steps = max(50, int(budget_s / max(dt / 50, 1e-9)))
-    steps = min(steps, 200000)
+    steps = min(max(50, int(budget_s / max(dt / 50, 1e-9))), 200000)
     t0 = time.perf_counter()
     o.rollout(table, steps)
     dt = time.perf_counter() - t0
-    return {"value": E * n_agents * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d agents x %d steps (fixture cases, auto-reset) in %.1f s; C++ oracle, 1 thread. "
-                      "The reference's own Python step measured in the build container: ~2-5 k agent-steps/s/core "
-                      "(BASELINE.md section 2)" % (E, n_agents, steps, dt)}
+    return E * n_agents * steps, dt
+
+
+def cpu_baseline(n_agents, K, budget_s=8.0):
+    """CPU baseline beside the GPU number, on THIS host (the GPU box), bounded to ~20 s:
+      * kind "port": oracle/ca_oracle.cpp (C++ restatement of the reference step) on 1 core and on all cores
+        (independent processes, rates summed -- envs never interact);
+      * the reference's OWN Python env.step cannot run here (/root/reference is not on the GPU box): its rate measured in
+        the build container by oracle/time_reference.py (1 process and nproc processes, host stated) is attached from
+        profiles/r02_reference_cpu.json."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    s1, d1 = _port_leg((n_agents, K, budget_s, 0))
+    allv, procs = None, min(cores, 64)
+    try:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            res = pool.map(_port_leg, [(n_agents, K, budget_s, r) for r in range(procs)])
+        allv = sum(s / d for s, d in res)
+    except Exception as e:  # noqa: BLE001 -- the baseline must never take the bench line down
+        allv, procs = None, 0
+        sys.stderr.write("cpu_baseline all-cores leg failed: %r\n" % (e,))
+    out = {"value": allv if allv else s1 / d1, "unit": "agent-steps/s", "cores": procs if allv else 1, "kind": "port",
+           "host_logical_cores": cores, "single_core_value": s1 / d1,
+           "sample": "C++ oracle (oracle/ca_oracle.cpp), 64 envs x %d agents per process, fixture cases with auto-reset: "
+                     "1 process for %.1f s (%d agent-steps), then %d processes x ~%.0f s" % (n_agents, d1, s1, procs, budget_s)}
+    ref = os.path.join(REPO, "profiles", "r02_reference_cpu.json")
+    if os.path.exists(ref):
+        r = json.load(open(ref))
+        out["reference_python"] = {"kind": "reference", "where": "build container (the reference does not travel to the GPU box)",
+                                   "host": r["host"], "one_process": r["one_process"]["agent_steps_per_s"],
+                                   "all_cores": r["all_cores"]["agent_steps_per_s"], "cores": r["all_cores"]["cores"],
+                                   "script": "oracle/time_reference.py"}
+    return out
 
 
 def _time_launches(fn, n, torch, dev):
@@ -129,6 +157,8 @@ def main():
     ap.add_argument("--mode", choices=["step", "rollout"], default="step",
                     help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-warm-seconds", type=float, default=0.3,
+                    help="untimed steady-state warm-up on top of --warmup (launches until this much time has passed)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the rollout / two-stream extras (profiling runs: only the headline kernel is launched)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI)")
@@ -189,8 +219,18 @@ def main():
             for _ in range(n):
                 sim.step()
 
+    # ---- untimed: the caller's W warm-up steps, then launches until the device has been busy for >= 0.3 s (clocks
+    # and caches in steady state whatever W was), and one pass through the statistics reduction (its first call loads
+    # the reduce kernel's code object and, for N > 1, builds the RCCL communicator)
     run(a.warmup)
     torch.cuda.synchronize(dev)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < a.min_warm_seconds:
+        run(50)
+        torch.cuda.synchronize(dev)
+    reduce_episode_stats(sim.episode_stats(), world)
+    torch.cuda.synchronize(dev)
+    # ---- timed: EXACTLY a.steps steps between barrier + synchronize on both sides; nothing else inside
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -199,17 +239,18 @@ def main():
     ev0.record()            # same stream the kernels are launched on (torch's current stream)
     run(a.steps)
     ev1.record()
-    stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective: 8 counters
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
     gpu_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+        wall, gpu_ms = float(tmax[0].item()), float(tmax[1].item())
+    stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective (8 counters), outside the clock
+    torch.cuda.synchronize(dev)
+    kernel_name = nat.lib().cagpu_last_kernel().decode()
 
     if rank == 0:
         agent_steps = float(world) * E * N * a.steps
@@ -221,6 +262,8 @@ def main():
         out = {
             "metric": "agent-steps/sec at 4096 envs x 10 agents (RVO)", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+            "event_ms_per_step": gpu_ms / a.steps,   # HIP events around the same K steps (device time only)
+            "suspect": bool(abs(wall * 1e3 - gpu_ms) > 0.2 * gpu_ms),  # host wall clock and device time disagree by > 20 %
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]-shaped at the metric size: %d envs/GPU x %d agents, RVOPolicy(ORCA) + "
                                    "UnicycleDynamics + OtherAgentsStatesSensor K=%d closest_first, DT=0.1, "
@@ -229,9 +272,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic_bytes(E, N) if a.mode == "step" else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_rocprof_summary.md)",
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02_rocprof_summary.md)",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "ca_kernel<256, false, 10, false, true, 64, 4>", "avg_launch_us": kern_s * 1e6,
+                         "kernel": kernel_name, "avg_launch_us": kern_s * 1e6,
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
         }

@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcagpu.so")
+# CAGPU_LIB: load another build of the same ABI (the -DCAGPU_ABLATE experiment build of scratch/); the library itself
+# reads no environment variable
+LIB_PATH = os.environ.get("CAGPU_LIB") or os.path.join(HERE, "libcagpu.so")
 
 # ---- constants mirrored from include/cagpu.h
 CA_OK, CA_EINVAL, CA_EUNSUPPORTED, CA_ELAUNCH, CA_ENODEVICE = 0, -1, -2, -3, -4
@@ -66,7 +68,7 @@ class CaNet(C.Structure):
     _fields_ = [(n, _P) for n in NET_FIELDS]
 
 
-EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
+EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
            "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c")
 
 _lib = None
@@ -99,9 +101,10 @@ def lib():
     L.cagpu_ga3c.argtypes = [PP, PS, _P, C.POINTER(CaNet), _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
-        if n not in ("cagpu_last_error",):
+        if n not in ("cagpu_last_error", "cagpu_last_kernel"):
             getattr(L, n).restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
+    L.cagpu_last_kernel.restype = C.c_char_p
     _lib = L
     return L
 

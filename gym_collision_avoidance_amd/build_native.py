@@ -18,16 +18,26 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [SRC, os.path.join(HERE, "csrc", "cagpu_g16.inc"), os.path.join(HERE, "csrc", "cagpu_grouplp.inc"), os.path.join(HERE, "csrc", "cagpu_scan.inc"),
+    deps = [SRC, os.path.join(HERE, "csrc", "cagpu_grouplp.inc"), os.path.join(HERE, "csrc", "cagpu_scan.inc"),
             os.path.join(HERE, "csrc", "cagpu_ga3c.inc"), os.path.join(REPO, "include", "cagpu.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, variant=None):
+    """variant None: the product library libcagpu.so.  variant "knobs" / "ablate": an EXPERIMENT build next to it
+    (libcagpu_knobs.so / libcagpu_ablate.so, -DCAGPU_KNOBS / -DCAGPU_ABLATE: geometry overrides from CAGPU_* environment
+    variables, in-kernel phase timers), loaded only by scratch/ scripts through CAGPU_LIB; never the product file."""
+    if variant is None and not force and not needs_build():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    out = OUT if variant is None else os.path.join(HERE, "libcagpu_%s.so" % variant)
+    extra = [] if variant is None else ["-DCAGPU_%s" % variant.upper()]
+    cmd = [hipcc] + FLAGS + extra + [SRC, "-o", out]
+    if variant is not None:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return out
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -35,4 +45,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    build(force=True, verbose=True, variant=sys.argv[1] if len(sys.argv) > 1 else None)

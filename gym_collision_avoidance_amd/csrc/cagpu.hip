@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <type_traits>
 
 #include "cagpu.h"
@@ -59,6 +60,7 @@ struct KArgs {
   int32_t n_steps, mode, stage_obs;
   int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
   int32_t col_stride; // columns of the per-(agent, slot) LDS tiles: ROW, or N for single-env tiles (N > 32)
+  int32_t aw_shift;  // the workgroup's agent wave = (blockIdx.x >> aw_shift) % (waves per workgroup); < 0: wave 0
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -335,6 +337,7 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 // Everything the phases exchange lives in LDS; per-(agent, slot) arrays are [slot][ROW] columns so that a phase that
 // walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
 constexpr int ROW = 64;
+constexpr int AW_SHIFT_DEFAULT = -1;  // agent-wave rotation (see ca_kernel); -1 = always wave 0
 constexpr int KEY_NONE = 2147483647;  // sort key of a pair that is not sensed (self, beyond the sensing horizon)
 #ifdef CAGPU_ABLATE
 #define AB(bit) (k.ablate & (bit))
@@ -350,8 +353,11 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 #include "cagpu_scan.inc"
 #include "cagpu_ga3c.inc"
 
-// fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays)
-__host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) { return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4); }
+// fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays) + the
+// linearProgram3 queue (length + up to ROW entries)
+__host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) {
+  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 1) * 4);
+}
 // union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
 // the registers of the solving group)
 __host__ __device__ inline size_t lds_orca_bytes(int N, int cs = ROW) {
@@ -387,9 +393,8 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.flags &= ~0x3Fu;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64, int TE = 0>
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int TE = 0>
 __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) {  // n-step: <= 128 VGPRs (4 waves / SIMD)
-  constexpr int ROW = RW;  // agent slots of the tile (shadows the default): 64, or 32 for half-size tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
@@ -399,8 +404,12 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
-  const bool wave0 = tid < ROW;
-  // identity of the agent on this lane (meaningful on wave 0 only)
+  // The AGENT WAVE of the workgroup runs the one-lane-per-agent phases.  Which wave that is rotates with the workgroup
+  // id: the dispatcher deals the waves of a workgroup to the SIMDs of a CU in order, so with a fixed choice the heavy
+  // waves of all co-resident workgroups pile up on the same SIMD (profiles/r02_kernel_geometry.md).
+  const int aw = (k.aw_shift >= 0) ? static_cast<int>((blockIdx.x >> k.aw_shift) & (NT / 64 - 1)) : 0;
+  const bool wave0 = (tid >> 6) == aw;
+  // identity of the agent on this lane (meaningful on the agent wave only)
   const int lane = tid & (ROW - 1);
   const int le = lane / N, a = lane - le * N;
   const long env0 = static_cast<long>(blockIdx.x) * tile_envs;
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   float* sh_vry = sh_vrx + ROW;
   float* sh_fprx = sh_vry + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
+  int* sh_q3 = reinterpret_cast<int*>(sh_fpry + ROW);  // linearProgram3 queue: [0] = length, [1 ..] = entries
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
   // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
     int tid_l = threadIdx.x;
     if (MULTI) asm volatile("" : "+v"(tid_l));
     const int tid = tid_l;
-    const bool wave0 = tid < ROW;
+    const bool wave0 = (tid >> 6) == aw;
     const int lane = tid & (ROW - 1);
     const int le = lane / N, a = lane - le * N;
     const long e = env0 + le;
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         sh_fvy[lane] = static_cast<float>(r.vy);
         sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
         sh_q[lane] = rvo ? 1 : 0;
-        sh_sense[lane] = 0;  // [0]: length of the linearProgram3 queue, [1..]: its entries (dead as sense flags here)
+        if (lane == 0) sh_q3[0] = 0;
         if (rvo) {
           const double vx = r.gx - r.px, vy = r.gy - r.py;
           const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
@@ -612,18 +622,18 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
                 sh_vry[agf] = v.y;
                 // infeasible (4.6 % of the queries at N = 10): queue the agent for the linearProgram3 pass below instead
                 // of solving it here, where it would stall the sibling groups of this wave for ~10 k cycles
-                if (failf != NOFAIL) sh_sense[1 + atomicAdd(&sh_sense[0], 1)] = agf | (failf << 8);
+                if (failf != NOFAIL) sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = agf | (failf << 8);
               }
             }
           }
           __syncthreads();
-          const int n3 = any_rvo ? sh_sense[0] : 0;
+          const int n3 = any_rvo ? sh_q3[0] : 0;
           if (n3 > 0 && !AB(2)) {  // workgroup-uniform
             // queue entry k goes to wave k % (number of waves) first: infeasible agents are solved side by side
             const int jl = tid & (GS - 1), g = tid / GS;
             constexpr int GPW = 64 / GS;  // groups per wave
             for (int q3 = (g % GPW) * (NT / 64) + (g / GPW); q3 < n3; q3 += GROUPS) {
-              const int ent = sh_sense[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
+              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
               const int nf = sh_nb[agf];
               const float4 ln = Lmat[((jl < nf) ? jl : 0) * CS + agf];
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
@@ -1071,8 +1081,6 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   }
 }
 
-#include "cagpu_g16.inc"
-
 // ---------------------------------------------------------------- stand-alone ORCA (rvo2 doStep replacement)
 struct OrcaArgs {
   int32_t num_envs, num_agents, max_nb;
@@ -1145,23 +1153,67 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   return CA_OK;
 }
 
-template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int RW = 64, int TE = 0>
+// ---- launch plan.  Everything that selects a kernel instantiation or a tile geometry is decided here from the
+// arguments and the device's CU count alone (no environment variables in the product build: -DCAGPU_KNOBS adds the
+// experiment knobs of scratch/, parsed once; -DCAGPU_ABLATE also the in-kernel phase timers).
+thread_local char g_last_kernel[160] = "";
+
+int device_cus() {  // CU count of the current device, cached per device id
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int c = cache[dev].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cache[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
+struct Knobs {  // experiment overrides (-DCAGPU_ABLATE builds only); -1 / 0 = not set
+  int tile = 0, nt = 0, stage = -1, no_nc = 0, rollout_fused = 0, aw_shift = -2;
+};
+const Knobs& knobs() {
+#if defined(CAGPU_ABLATE) || defined(CAGPU_KNOBS)
+  static const Knobs kn = [] {
+    Knobs q;
+    if (const char* e = std::getenv("CAGPU_TILE")) q.tile = std::atoi(e);
+    if (const char* e = std::getenv("CAGPU_NT")) q.nt = std::atoi(e);
+    if (std::getenv("CAGPU_STAGE")) q.stage = 1;
+    if (std::getenv("CAGPU_NOSTAGE")) q.stage = 0;
+    if (std::getenv("CAGPU_NO_NC")) q.no_nc = 1;
+    if (std::getenv("CAGPU_ROLLOUT_FUSED")) q.rollout_fused = 1;
+    if (const char* e = std::getenv("CAGPU_AW_SHIFT")) q.aw_shift = std::atoi(e);
+    return q;
+  }();
+  return kn;
+#else
+  static const Knobs kn;
+  return kn;
+#endif
+}
+
+template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int TE = 0>
 int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
-  static thread_local size_t lds_limit[16] = {0};
+  static std::atomic<size_t> lds_limit[64];
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
-  size_t& lds_limit_set = lds_limit[dev_id & 15];
-  if (lds_limit_set == 0) lds_limit_set = 48 * 1024;
-  if (total > lds_limit_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, RW, TE>),
+  std::atomic<size_t>& lim = lds_limit[dev_id & 63];
+  size_t have = lim.load(std::memory_order_relaxed);
+  if (have == 0) have = 48 * 1024;
+  if (total > have) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel<NT, STAGE, NC, MULTI, RO, TE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    lds_limit_set = total;
+    lim.store(total, std::memory_order_relaxed);
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, RW, TE>), dim3(grid), dim3(NT), total, st, k);
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_kernel<%d, %s, %d, %s, %s, %d> grid=%u lds=%zu tile_envs=%d aw_shift=%d",
+                NT, STAGE ? "true" : "false", NC, MULTI ? "true" : "false", RO ? "true" : "false", TE, grid, total,
+                tile_envs, k.aw_shift);
+  hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, TE>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
@@ -1169,8 +1221,8 @@ int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
 
 template <int NT, bool STAGE, int NC, bool MULTI, int TE = 0>
 int launch_main4(const KArgs& k, size_t total, hipStream_t st) {
-  if (k.mode == MODE_STEP && k.table && k.reset_obs) return launch_main5<NT, STAGE, NC, MULTI, true, 64, TE>(k, total, st);
-  return launch_main5<NT, STAGE, NC, MULTI, false, 64, TE>(k, total, st);
+  if (k.mode == MODE_STEP && k.table && k.reset_obs) return launch_main5<NT, STAGE, NC, MULTI, true, TE>(k, total, st);
+  return launch_main5<NT, STAGE, NC, MULTI, false, TE>(k, total, st);
 }
 
 template <int NT, bool STAGE, int NC, int TE = 0>
@@ -1182,7 +1234,7 @@ int launch_main3(const KArgs& k, size_t total, hipStream_t st) {
 template <int NT, bool STAGE>
 int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
   if constexpr (NT <= 256) {  // the 512-thread geometry exists for large N only
-    if (k.p.num_agents == 10 && !std::getenv("CAGPU_NO_NC")) {  // N and the tile size compiled in
+    if (k.p.num_agents == 10 && !knobs().no_nc) {  // N and the tile size compiled in
       if (k.tile_envs == ROW / 10) return launch_main3<NT, STAGE, 10>(k, total, st);
       if (k.tile_envs == 4) return launch_main3<NT, STAGE, 10, 4>(k, total, st);
     }
@@ -1202,20 +1254,15 @@ int launch_main(const KArgs& k, hipStream_t st) {
   // Staging the tile's observation block in LDS (one coalesced copy-out) wins while every workgroup of the launch is
   // resident at once; for larger batches the smaller footprint without it (5 instead of 3 workgroups per CU at
   // N = 10) hides more latency: 145 vs 167 us at 32768 envs, 32.9 vs 30.7 us at 4096 (profiles/r01_kernel_geometry.md).
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = device_cus();
   const long wgs = (static_cast<long>(k.p.num_envs) + k.tile_envs - 1) / k.tile_envs;
   // (a fourth staged workgroup per CU fits the LDS on paper at N = 10 but measured 44 us at 5120 envs against 35 us for
   // the unstaged layout, so the staged layout is only kept up to three per CU)
   const long per_cu = static_cast<long>((160 * 1024) / total);
   const long resident_staged = (per_cu < 3 ? per_cu : 3) * n_cu;
-  const bool crowded = wgs > resident_staged && !std::getenv("CAGPU_STAGE");
-  if (total > 64 * 1024 || crowded || std::getenv("CAGPU_NOSTAGE")) {  // give up the staging area
+  bool crowded = wgs > resident_staged;
+  if (knobs().stage == 1) crowded = false;
+  if (total > 64 * 1024 || crowded || knobs().stage == 0) {  // give up the staging area
     un_sense = lds_sense_bytes(N, W, 0, tti, cs);
     stage = false;
     total = lds_fixed_bytes() + (un_orca > un_sense ? un_orca : un_sense);
@@ -1226,7 +1273,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
   // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps).
   const long lds_cap = static_cast<long>((160 * 1024) / total);
   const long fused_resident = (lds_cap < 4 ? lds_cap : 4) * n_cu;
-  if (k.mode == MODE_STEP && k.n_steps > 1 && wgs > fused_resident && !std::getenv("CAGPU_ROLLOUT_FUSED")) {
+  if (k.mode == MODE_STEP && k.n_steps > 1 && wgs > fused_resident && !knobs().rollout_fused) {
     KArgs k1 = k;
     k1.n_steps = 1;
     for (int i = 0; i < k.n_steps; ++i) {
@@ -1238,39 +1285,10 @@ int launch_main(const KArgs& k, hipStream_t st) {
   return stage ? launch_main2<NT, true>(k, total, st) : launch_main2<NT, false>(k, total, st);
 }
 
-// ---- launcher of the 16-lane-group kernel (num_agents <= 16)
-template <int NC, bool MULTI>
-int launch_g16(const KArgs& k, hipStream_t st) {
-  const int N = k.p.num_agents, W = 6 + 7 * k.p.max_obs;
-  int epw = 20 / N;  // ~20 agents (5 waves) per workgroup
-  if (epw < 1) epw = 1;
-  if (const char* e = std::getenv("CAGPU_EPW")) epw = std::atoi(e);  // experiments
-  if (epw * N > TMAX16) epw = TMAX16 / N;
-  constexpr int TM = NC ? ((20 / NC) > 0 ? (20 / NC) * NC : NC) : TMAX16;
-  if (NC) epw = TM / NC;  // the specialised instantiation has its tile size baked in
-  KArgs kk = k;
-  kk.stage_obs = epw;
-  const int T = epw * N;
-  const int nt = ((T + 3) / 4) * 64;
-  const size_t total = align16(sizeof(G16Lds<TM>)) + align16(static_cast<size_t>(TM) * W * 4);
-  if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu: max_obs too large for the LDS staging area%s");
-  if (total > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ca_kernel16<NC, MULTI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total));
-    if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  }
-  const unsigned grid = static_cast<unsigned>((k.p.num_envs + epw - 1) / epw);
-  hipLaunchKernelGGL((ca_kernel16<NC, MULTI>), dim3(grid), dim3(nt), total, st, kk);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
-  return CA_OK;
-}
-
 // Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
 // single-step kernel (30.7 us; 128 -> 39, 384 / 512 -> 40) and the n-step rollout kernel (22.2 us / step; 128 -> 28.8).
 // The rollout kernel only reaches that since the build disables machine LICM (build_native.py): hoisted loop invariants
 // had cost it 217 VGPRs (2 waves / SIMD: the 683 workgroups of 256 threads no longer fit at once) instead of 139.
-// CAGPU_NT overrides for experiments.
 int launch_any(const KArgs& k0, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   KArgs k = k0;
@@ -1280,31 +1298,16 @@ int launch_any(const KArgs& k0, void* stream) {
   // N = 10: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all co-resident, evenly
   // spread): 27.3 vs 30.9 us at 4096 envs, 23.3 vs 27.6 at 2048; beyond that the 6-env tile wins
   // (profiles/r01_kernel_geometry.md)
-  if (N == 10 && k.mode == MODE_STEP && !std::getenv("CAGPU_TILE")) {
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    static thread_local int cu_cache[16] = {0};
-    if (hipGetDevice(&dev) == hipSuccess) {
-      if (!cu_cache[dev & 15] && hipGetDeviceProperties(&prop, dev) == hipSuccess) cu_cache[dev & 15] = prop.multiProcessorCount;
-      if (cu_cache[dev & 15] > 0) cus = cu_cache[dev & 15];
-    }
-    if ((static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * cus) k.tile_envs = 4;
+  if (N == 10 && k.mode == MODE_STEP && !knobs().tile) {
+    if ((static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * device_cus()) k.tile_envs = 4;
   }
-  if (const char* e = std::getenv("CAGPU_TILE")) {  // experiments
-    const int t = std::atoi(e);
-    if (t >= 1 && t < k.tile_envs) k.tile_envs = t;
-  }
-  if (N <= G16 && std::getenv("CAGPU_G16") && k.p.sort_mode != CA_SORT_TIME_TO_IMPACT && !k.map.static_bits) {  // experimental 16-lane-group kernel (profiles/r01_kernel_geometry.md)
-    const bool multi = k.mode == MODE_STEP && k.n_steps > 1;
-    if (N == 10) return multi ? launch_g16<10, true>(k, st) : launch_g16<10, false>(k, st);
-    return multi ? launch_g16<0, true>(k, st) : launch_g16<0, false>(k, st);
-  }
-  int nt = 256;
-  if (const char* e = std::getenv("CAGPU_NT")) nt = std::atoi(e);  // experiments
+  if (knobs().tile >= 1 && knobs().tile < k.tile_envs) k.tile_envs = knobs().tile;
+  k.aw_shift = AW_SHIFT_DEFAULT;
+  if (knobs().aw_shift > -2) k.aw_shift = knobs().aw_shift;
   // N > 32: the tile is a single env whose N^2 pair items (and N wave-wide linear programs) keep 8 waves busy, and
   // its LDS footprint allows only one or two workgroups per CU anyway
-  if (N > 32 && !std::getenv("CAGPU_NT")) nt = 512;
-  if (nt <= 128) return launch_main<128>(k, st);
+  int nt = (N > 32) ? 512 : 256;
+  if (knobs().nt) nt = knobs().nt;
   if (nt <= 256) return launch_main<256>(k, st);
   return launch_main<512>(k, st);
 }
@@ -1336,6 +1339,8 @@ extern "C" {
 int cagpu_version(void) { return CAGPU_VERSION; }
 
 const char* cagpu_last_error(void) { return g_err; }
+
+const char* cagpu_last_kernel(void) { return g_last_kernel; }
 
 int cagpu_reset(const CaParams* p, const CaState* s, const CaOut* o, const double* cases, const double* headings,
                 const uint8_t* mask, void* stream) {

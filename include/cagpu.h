@@ -165,6 +165,10 @@ typedef struct CaNet {
 
 int cagpu_version(void);
 const char *cagpu_last_error(void);
+/* Introspection for tests / bench.py: the kernel instantiation and launch geometry the last cagpu_step / rollout /
+ * reset / observe call of THIS thread selected, e.g. "ca_kernel<256, false, 10, false, true, 4> grid=1024 ...".
+ * The selection depends only on the call's arguments and the device's CU count (never on the environment). */
+const char *cagpu_last_kernel(void);
 
 /* Replaces: Agent.reset (agent.py:59-138) for every agent of the envs with mask[e] != 0 (mask NULL =
  * all), in the EVALUATE_MODE form of test_cases.py:545-590 (heading toward the goal unless

@@ -198,17 +198,29 @@ def _compare_reset(o, g):
         np.testing.assert_allclose(g.state[n].cpu().numpy().reshape(-1), o.s[n], rtol=0, atol=1e-9, err_msg=n)
 
 
+def _swap_cases(table):
+    """fixture cases holding a pair of agents that exchange places exactly (start_i == goal_j and start_j == goal_i):
+    the two meet head-on on one line, a perfectly symmetric ORCA problem whose resolution is decided by round-off"""
+    s, g = table[:, :, 0:2], table[:, :, 2:4]
+    a = np.abs(s[:, :, None, :] - g[:, None, :, :]).max(axis=-1) < 1e-9       # [C, i, j]: start_i == goal_j
+    both = a & np.swapaxes(a, 1, 2)
+    both &= ~np.eye(table.shape[1], dtype=bool)[None]
+    return both.any(axis=(1, 2))
+
+
 def test_free_running_vs_oracle_10_agents():
-    """no re-injection: 256 envs x 10 agents x 200 steps with auto-reset.  This comparison is ill-posed for a few
-    percent of the fixture cases: agents that start exactly on a common axis (the "swap" cases) meet head-on in a
+    """no re-injection: 256 envs x 10 agents x 200 steps with auto-reset.  This comparison is ill-posed for the
+    fixture cases in which two agents swap places exactly (71 of the 500 ten-agent cases): they meet head-on in a
     perfectly symmetric configuration, which ORCA resolves by amplifying lateral round-off noise ~12x per step
     (measured: 4e-16 -> 2e-5 in 11 steps, in the CPU oracle as much as on the GPU).  The seed of that noise is the
-    last bit of atan2 at +-pi, where ROCm's libm and glibc differ, so those envs legitimately take different
-    (mirror-image) paths.  Everything else must agree: >= 95 % of envs identical in masks and within 1e-5 in
-    position, and the episode statistics within a few episodes."""
+    last bit of atan2 at +-pi, where ROCm's libm and glibc differ, so those envs may legitimately take different
+    (mirror-image) paths.  Bar: every env that disagrees has been through such a swap case; every other env agrees in
+    masks exactly and in position within 1e-5; and the two populations' episode statistics stay within a few episodes."""
     nat, core, orc = _mods()
     N, E, steps = 10, 256, 200
     table = gu.fixtures(N)
+    swap = _swap_cases(table)
+    assert 50 < swap.sum() < 100
     o, g = _pair(E, N)
     o.s["policy"][:] = orc.POL_RVO
     g.set_plugins(nat.POL_RVO)
@@ -222,9 +234,15 @@ def test_free_running_vs_oracle_10_agents():
     gf = g.state["flags"].cpu().numpy().reshape(E, N).astype(np.uint32) & MASK
     of = (o.s["flags"] & MASK).reshape(E, N)
     env_ok = (gf == of).all(axis=1)
-    pos_err = np.abs(g.state["pos_x"].cpu().numpy() - o.s["pos_x"].reshape(E, N)).max(axis=1)
-    assert env_ok.mean() >= 0.95, "flags agree on %.3f of envs" % env_ok.mean()
-    assert (pos_err < TOL).mean() >= 0.95, "positions agree on %.3f of envs" % (pos_err < TOL).mean()
+    pos_err = np.maximum(np.abs(g.state["pos_x"].cpu().numpy() - o.s["pos_x"].reshape(E, N)).max(axis=1),
+                         np.abs(g.state["pos_y"].cpu().numpy() - o.s["pos_y"].reshape(E, N)).max(axis=1))
+    # cases env e has been through so far (either run): (e + k E) % 500 for k = 0 .. resets taken
+    resets = np.maximum(o.s["reset_count"], g.state["reset_count"].cpu().numpy())
+    excused = np.array([swap[(e + np.arange(resets[e] + 1) * E) % 500].any() for e in range(E)])
+    diverged = ~env_ok | ~(pos_err < TOL)
+    assert not (diverged & ~excused).any(), "envs %s diverged without having met a swap case (pos err %s)" % (
+        np.nonzero(diverged & ~excused)[0][:10], pos_err[diverged & ~excused][:10])
+    assert env_ok.mean() >= 0.9 and (pos_err < TOL).mean() >= 0.9, (env_ok.mean(), (pos_err < TOL).mean())
     gs, os_ = g.episode_stats().cpu().numpy(), o.s["env_stats"].sum(axis=0)
     assert abs(gs[0] - os_[0]) <= 4 and abs(gs[1] - os_[1]) <= 4
 
@@ -249,6 +267,84 @@ def test_rollout_equals_repeated_steps(E, T):
     assert torch.equal(sims[0].obs, sims[1].obs)
     assert torch.equal(sims[0].rewards, sims[1].rewards)
     assert torch.equal(sims[0].done, sims[1].done)
+
+
+# ---------------------------------------------------------------- the metric geometry itself (4096 x 10 and its neighbours)
+def _expected_kernel(E, multi):
+    """the instantiation the launcher must pick on a 256-CU MI355X for N = 10 with precomputed reset observations:
+    4-env tiles while ceil(E / 4) <= 4 x CUs; the staged observation block only while <= 3 workgroups per CU"""
+    wgs4 = (E + 3) // 4
+    te = 4 if wgs4 <= 4 * 256 else 0
+    wgs = wgs4 if te == 4 else (E + 5) // 6
+    stage = wgs <= 3 * 256
+    return "ca_kernel<256, %s, 10, %s, true, %d>" % ("true" if stage else "false", "true" if multi else "false", te)
+
+
+@pytest.mark.parametrize("E", [3073, 4095, 4096])
+def test_metric_geometry_step_vs_oracle(E):
+    """The exact kernel instantiation bench.py times (4-env tiles, unstaged, N compiled in, precomputed reset
+    observations), re-injected from the oracle for 30 steps with auto-reset: masks exact, floats within 1e-5."""
+    nat, core, orc = _mods()
+    N, steps = 10, 30
+    table = gu.fixtures(N)
+    o, g = _pair(E, N)
+    o.s["policy"][:] = orc.POL_RVO
+    g.set_plugins(nat.POL_RVO)
+    g.set_fixture_table(table)
+    cases = table[np.arange(E) % 500]
+    o.reset(cases)
+    g.reset(cases)
+    _compare_reset(o, g)
+    # start mid-episode so that time-outs / goals / collisions / auto-resets all occur within the compared window
+    o.rollout(table, 55)
+    for t in range(steps):
+        _upload(o, g)
+        o.rollout(table, 1)
+        g.step()
+        assert nat.lib().cagpu_last_kernel().decode().startswith(_expected_kernel(E, False)), nat.lib().cagpu_last_kernel()
+        _compare(o, g, what="E=%d step %d" % (E, t))
+        np.testing.assert_allclose(g.state["env_stats"].cpu().numpy(), o.s["env_stats"], rtol=0, atol=1e-6)
+    assert o.s["env_stats"][:, 0].sum() > E // 8       # plenty of episodes ended inside the window
+
+
+@pytest.mark.parametrize("E", [3073, 4096])
+def test_metric_geometry_rollout_vs_oracle(E):
+    """cagpu_rollout (the fused n-step instantiation at the metric geometry) against the ORACLE's rollout: both start
+    from the same state, run 3 steps on their own, are compared, and the oracle's state is re-injected (a free run of 3
+    steps cannot amplify the libm round-off of a symmetric encounter beyond the 1e-5 bar)."""
+    nat, core, orc = _mods()
+    N = 10
+    table = gu.fixtures(N)
+    o, g = _pair(E, N)
+    o.s["policy"][:] = orc.POL_RVO
+    g.set_plugins(nat.POL_RVO)
+    g.set_fixture_table(table)
+    cases = table[np.arange(E) % 500]
+    o.reset(cases)
+    g.reset(cases)
+    o.rollout(table, 60)
+    for r in range(10):
+        _upload(o, g)
+        o.rollout(table, 3)
+        g.rollout(3)
+        assert nat.lib().cagpu_last_kernel().decode().startswith(_expected_kernel(E, True)), nat.lib().cagpu_last_kernel()
+        _compare(o, g, what="E=%d rollout round %d" % (E, r))
+        np.testing.assert_allclose(g.state["env_stats"].cpu().numpy(), o.s["env_stats"], rtol=0, atol=1e-6)
+    assert o.s["env_stats"][:, 0].sum() > E // 8
+
+
+def test_bench_kernel_is_the_tested_kernel():
+    """bench.py's workload (4096 x 10, fixture table, reset observations precomputed) selects the instantiation the two
+    tests above hold against the oracle"""
+    nat, core, orc = _mods()
+    g = core.BatchedSim(core.make_params(4096, 10))
+    g.set_plugins(nat.POL_RVO)
+    g.set_fixture_table(gu.fixtures(10))
+    g.reset_from_table()
+    g.step()
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<256, false, 10, false, true, 4> grid=1024")
+    g.rollout(5)
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<256, false, 10, true, true, 4> grid=1024")
 
 
 # ---------------------------------------------------------------- ORCA stage alone (rvo2 replacement)
@@ -435,7 +531,12 @@ def test_full_size_properties():
     f = g.state["flags"].cpu().numpy().astype(np.uint32)
     done = (f & (nat.AT_GOAL | nat.OUT_OF_TIME | nat.IN_COLLISION)) != 0
     assert np.array_equal(done, (f & nat.DONE) != 0)
-    assert np.array_equal(done.astype(np.uint8), g.done.cpu().numpy()) or True  # done buffer holds terminal-step values
+    # o->done holds the values of the step just taken: for an env that auto-reset in that step they are the terminal
+    # step's (all done) while the state already belongs to the new episode; everywhere else buffer and state agree
+    fresh = (g.state["episode_step"].cpu().numpy() == 0)
+    assert np.array_equal(done.astype(np.uint8)[~fresh], g.done.cpu().numpy()[~fresh])
+    assert g.done.cpu().numpy()[fresh].all() and g.game_over.cpu().numpy()[fresh].all()
+    assert not done[fresh].any()
     obs = g.obs.cpu().numpy()
     assert np.all(obs[..., 1] == N - 1)                      # everyone observes all 9 others
     oa = obs[..., 6:].reshape(E, N, N - 1, 7)
