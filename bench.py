@@ -219,28 +219,36 @@ def main():
             for _ in range(n):
                 sim.step()
 
-    # ---- untimed: the caller's W warm-up steps, then launches until the device has been busy for >= 0.3 s (clocks
-    # and caches in steady state whatever W was), and one pass through the statistics reduction (its first call loads
-    # the reduce kernel's code object and, for N > 1, builds the RCCL communicator)
+    # ---- untimed: one pass through the statistics reduction (its first call loads the reduce kernel's code object
+    # and, for N > 1, builds the RCCL communicator) and through the timing events (torch creates them lazily), the
+    # caller's W warm-up steps, then launches until the device has been busy for >= 0.3 s (clocks and caches in steady
+    # state whatever W was).  The warm-up ends directly at the synchronize that opens the timed region: no idle gap in
+    # which the device could drop its clocks.
+    import gc
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
+    reduce_episode_stats(sim.episode_stats(), world)
     run(a.warmup)
     torch.cuda.synchronize(dev)
+    gc.collect()
+    gc.disable()
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < a.min_warm_seconds:
-        run(50)
+        run(50 if a.mode == "step" else a.steps)
         torch.cuda.synchronize(dev)
-    reduce_episode_stats(sim.episode_stats(), world)
-    torch.cuda.synchronize(dev)
     # ---- timed: EXACTLY a.steps steps between barrier + synchronize on both sides; nothing else inside
     if world > 1:
         dist.barrier()
+        run(20 if a.mode == "step" else a.steps)   # the barrier idled the device: bring it back before the clock starts
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
     ev0.record()            # same stream the kernels are launched on (torch's current stream)
+    t0 = time.perf_counter()
     run(a.steps)
     ev1.record()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         dist.barrier()
     gpu_ms = ev0.elapsed_time(ev1)

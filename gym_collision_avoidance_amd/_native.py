@@ -27,7 +27,8 @@ class CaParams(C.Structure):
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
-                                          "rvo_time_horizon", "rvo_collab_coeff", "max_heading_change")]
+                                          "rvo_time_horizon", "rvo_collab_coeff", "max_heading_change",
+                                          "reward_collision_wall", "rvo_dt")]
 
 
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",

@@ -31,7 +31,8 @@ def build(force=False, verbose=False, variant=None):
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = OUT if variant is None else os.path.join(HERE, "libcagpu_%s.so" % variant)
-    extra = [] if variant is None else ["-DCAGPU_%s" % variant.upper()]
+    # "ablate_fast" / "knobs_fast": the same with only the N = 10 unstaged instantiations compiled (quick iterations)
+    extra = [] if variant is None else ["-DCAGPU_%s" % v.upper() for v in variant.split("_")]
     cmd = [hipcc] + FLAGS + extra + [SRC, "-o", out]
     if variant is not None:
         if verbose:

@@ -24,7 +24,8 @@ def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, 
                 game_over_mode=nat.OVER_ALL_DONE, rvo_max_neighbors=None, near_goal_threshold=0.2,
                 getting_close_range=0.2, sensing_horizon=math.inf, reward_at_goal=1.0, reward_collision=-0.25,
                 reward_time_step=0.0, reward_wiggly=0.0, wiggly_threshold=math.inf, reward_min=None, reward_max=None,
-                rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3, obs_clip=None):
+                rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3, obs_clip=None,
+                reward_collision_wall=-0.25, rvo_dt=None):
     """CaParams with the reference's Config defaults (config.py:28-86) for an EvaluateConfig-style run."""
     p = nat.CaParams()
     p.num_envs, p.num_agents = int(num_envs), int(num_agents)
@@ -37,11 +38,13 @@ def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, 
     p.reward_at_goal, p.reward_collision, p.reward_time_step = reward_at_goal, reward_collision, reward_time_step
     p.reward_wiggly, p.wiggly_threshold = reward_wiggly, wiggly_threshold
     # collision_avoidance_env.py:589-599: clip bounds = min/max of the possible reward values
-    vals = [reward_at_goal, reward_collision, reward_time_step, reward_collision, reward_wiggly]
+    vals = [reward_at_goal, reward_collision, reward_time_step, reward_collision_wall, reward_wiggly]
     p.reward_min = min(vals) if reward_min is None else reward_min
     p.reward_max = max(vals) if reward_max is None else reward_max
     p.rvo_time_horizon, p.rvo_collab_coeff = rvo_time_horizon, rvo_collab_coeff
     p.max_heading_change = max_heading_change
+    p.reward_collision_wall = reward_collision_wall
+    p.rvo_dt = dt if rvo_dt is None else rvo_dt   # RVOPolicy.py:13: Config.DT, whatever dt a later step() is called with
     return p
 
 
@@ -77,6 +80,7 @@ class BatchedSim(object):
                              game_over=self.game_over.data_ptr(),
                              actions=self.actions.data_ptr() if record_actions else None)
         self._ar = None
+        self._fast_args = None    # prebuilt ctypes arguments of the external-action-free step (see step())
         self._table = None
         self._keep = []
         self._map = None
@@ -158,6 +162,7 @@ class BatchedSim(object):
     def set_fixture_table(self, table, env_id_offset=0, case_stride=None):
         """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,
         test_cases.py:593-624): env e's k-th reset loads case (env_id_offset + e + k*case_stride) % C."""
+        self._fast_args = None
         if table is None:
             self._ar, self._table = None, None
             return
@@ -201,6 +206,7 @@ class BatchedSim(object):
         LaserScanSensor buffers with the reference's hard-coded parameters (LaserScanSensor.py:28-39).  With a map
         set, step() also tests wall collisions (collision_avoidance_env.py:494-506)."""
         bits = None
+        self._fast_args = None
         if static_map is not None:
             m = np.asarray(static_map).astype(bool)
             assert m.shape == (rows, cols), m.shape
@@ -228,6 +234,22 @@ class BatchedSim(object):
         return self.scan
 
     def step(self, ext_actions=None):
+        if ext_actions is None and not self._has_ga3c:
+            # env.step(None) with built-in policies only (env_utils.py:50): the per-step host path is one ctypes call
+            # with prebuilt arguments -- at ~20 us per launch the interpreter is otherwise on the critical path
+            fa = self._fast_args
+            if fa is None:
+                ar = None if self._ar is None else C.byref(self._ar)
+                if self._map is not None:
+                    fa = (self.lib.cagpu_step_map, (C.byref(self.p), C.byref(self._cs), C.byref(self._co), None, ar,
+                                                    C.byref(self._map)))
+                else:
+                    fa = (self.lib.cagpu_step, (C.byref(self.p), C.byref(self._cs), C.byref(self._co), None, ar))
+                self._fast_args = fa
+            rc = fa[0](*fa[1], torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                nat.check(rc)
+            return self.obs, self.rewards, self.game_over
         e = self._dev(ext_actions, torch.float64)
         if e is not None:
             assert tuple(e.shape) == (self.E, self.N, 2), e.shape

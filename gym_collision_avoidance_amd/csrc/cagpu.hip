@@ -60,7 +60,6 @@ struct KArgs {
   int32_t n_steps, mode, stage_obs;
   int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
   int32_t col_stride; // columns of the per-(agent, slot) LDS tiles: ROW, or N for single-env tiles (N > 32)
-  int32_t aw_shift;  // the workgroup's agent wave = (blockIdx.x >> aw_shift) % (waves per workgroup); < 0: wave 0
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -337,31 +336,40 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 // Everything the phases exchange lives in LDS; per-(agent, slot) arrays are [slot][ROW] columns so that a phase that
 // walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
 constexpr int ROW = 64;
-constexpr int AW_SHIFT_DEFAULT = -1;  // agent-wave rotation (see ca_kernel); -1 = always wave 0
 constexpr int KEY_NONE = 2147483647;  // sort key of a pair that is not sensed (self, beyond the sensing horizon)
 #ifdef CAGPU_ABLATE
 #define AB(bit) (k.ablate & (bit))
+#define DUP(bit) for (int rep_ = 0; rep_ < ((k.ablate & (bit)) ? 2 : 1); ++rep_)  // run an idempotent phase twice: its cost in situ
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_wgprof[1024 * 16];
 #define TICK(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); sh_prof[slot] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else
 #define AB(bit) false
+#define DUP(bit)
 #define TICK(slot) do {} while (0)
 #endif
+// Pair items w = 0 .. n_items-1 are dealt to the NT threads in rounds; odd rounds run BACKWARDS over the threads, so the
+// last, partial round lands on the highest waves and wave 0 -- the agent wave -- is free for its one-lane-per-agent work
+// while the other waves finish the pair phase (400 items on 256 threads: wave 0 has one round, waves 2 and 3 two).
+#define FOR_ITEMS_UPTO(w, count)                                                       \
+  for (int base_ = 0, odd_ = 0; base_ < (count); base_ += NT, odd_ ^= 1)              \
+    if (const int w = base_ + (odd_ ? (NT - 1 - tid) : tid); w < (count))
+#define FOR_PAIR_ITEMS(w) FOR_ITEMS_UPTO(w, n_items)
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
 #include "cagpu_scan.inc"
 #include "cagpu_ga3c.inc"
 
 // fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays) + the
-// linearProgram3 queue (length + up to ROW entries)
+// linearProgram3 queue (length + up to ROW entries) + the exchange area of lp3_wave8 (8 float4 per wave)
 __host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) {
-  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 1) * 4);
+  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 1) * 4) + 8 * 8 * 16;
 }
-// union, ORCA view: dist^2 [N][ROW] f32, half-planes [N-1][ROW] float4 (the projected lines of linearProgram3 live in
-// the registers of the solving group)
+// union, ORCA view: half-planes [N-1][CS] float4, the solution of every line's 1-D programme [N-1][CS] float2 + its
+// feasibility byte; the projected lines of linearProgram3 live in the registers of the solving group
+__host__ __device__ inline size_t lds_orca_lines(int N, int cs) { return static_cast<size_t>(cs) * (N > 1 ? N - 1 : 1); }
 __host__ __device__ inline size_t lds_orca_bytes(int N, int cs = ROW) {
-  return align16(static_cast<size_t>(cs) * N * 4) + static_cast<size_t>(cs) * (N > 1 ? N - 1 : 1) * 16;
+  return lds_orca_lines(N, cs) * (16 + 8) + align16(lds_orca_lines(N, cs));
 }
 // union, sensor view: p_orth / gap / time-to-impact [N][CS] f64, key i32, dist_2_other f32, rank u8,
 // obs staging [ROW*W] f32
@@ -404,12 +412,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   const int tile_n = tile_envs * N;
   const int n_items = tile_n * N;
   const int tid = threadIdx.x;
-  // The AGENT WAVE of the workgroup runs the one-lane-per-agent phases.  Which wave that is rotates with the workgroup
-  // id: the dispatcher deals the waves of a workgroup to the SIMDs of a CU in order, so with a fixed choice the heavy
-  // waves of all co-resident workgroups pile up on the same SIMD (profiles/r02_kernel_geometry.md).
-  const int aw = (k.aw_shift >= 0) ? static_cast<int>((blockIdx.x >> k.aw_shift) & (NT / 64 - 1)) : 0;
-  const bool wave0 = (tid >> 6) == aw;
-  // identity of the agent on this lane (meaningful on the agent wave only)
+  // Wave 0 is the workgroup's AGENT WAVE (one lane per agent).  It needs no rotation across workgroups: the dispatcher
+  // starts each workgroup of a CU on a different SIMD (scratch/hwid.hip: with 4 workgroups of 4 waves per CU every SIMD
+  // holds exactly one wave 0), and rotating the role measured no difference (profiles/r02_kernel_geometry.md).
+  const bool wave0 = tid < ROW;
+  // identity of the agent on this lane (meaningful on wave 0 only)
   const int lane = tid & (ROW - 1);
   const int le = lane / N, a = lane - le * N;
   const long env0 = static_cast<long>(blockIdx.x) * tile_envs;
@@ -447,13 +454,15 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   float* sh_fprx = sh_vry + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
   int* sh_q3 = reinterpret_cast<int*>(sh_fpry + ROW);  // linearProgram3 queue: [0] = length, [1 ..] = entries
+  float4* sh_x3 = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sh_q3) + align16(static_cast<size_t>(ROW + 1) * 4));
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
   // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
   const int CS = NC ? ROW : k.col_stride;
   // ORCA view of the union
-  float* dmat = reinterpret_cast<float*>(un);                                   // [N][CS]
-  float4* Lmat = reinterpret_cast<float4*>(un + align16(static_cast<size_t>(CS) * N * 4));  // [N-1][CS]
+  float4* Lmat = reinterpret_cast<float4*>(un);                                          // [N-1][CS] half-planes
+  float2* Rmat = reinterpret_cast<float2*>(Lmat + lds_orca_lines(N, CS));                // [N-1][CS] 1-D optimum on line i
+  uint8_t* okmat = reinterpret_cast<uint8_t*>(Rmat + lds_orca_lines(N, CS));             // [N-1][CS] line i feasible
   // sensor view of the union
   // p_orth and the collision gap stay float64 (they decide order / collisions); the sort bucket rint(100 d) is an
   // integer (int32, KEY_NONE = not sensed) and dist_2_other is only emitted as float32: 25 B per pair instead of 33.
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
     int tid_l = threadIdx.x;
     if (MULTI) asm volatile("" : "+v"(tid_l));
     const int tid = tid_l;
-    const bool wave0 = (tid >> 6) == aw;
+    const bool wave0 = tid < ROW;
     const int lane = tid & (ROW - 1);
     const int le = lane / N, a = lane - le * N;
     const long e = env0 + le;
@@ -534,50 +543,48 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         sh_fvx[lane] = static_cast<float>(r.vx);
         sh_fvy[lane] = static_cast<float>(r.vy);
         sh_frad[lane] = static_cast<float>((1 + 5e-2) * r.rad);  // RVOPolicy.py:71
-        sh_q[lane] = rvo ? 1 : 0;
-        if (lane == 0) sh_q3[0] = 0;
-        if (rvo) {
-          const double vx = r.gx - r.px, vy = r.gy - r.py;
-          const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
-          sh_fprx[lane] = static_cast<float>(sc * vx);
-          sh_fpry[lane] = static_cast<float>(sc * vy);
-          sh_fms[lane] = static_cast<float>(r.ps);
+        // compact list of the tile's ORCA queries: in steady state ~40 % of the agents are done and wait for their env's
+        // game over (EVALUATE_MODE), and pair items dealt over ALL agents would idle in 4 of 10 lanes of every wave
+        const unsigned long long qm = __ballot(rvo);
+        if (rvo) sh_q[__popcll(qm & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) {
+          sh_q3[0] = 0;
+          sh_q3[ROW + 1] = __popcll(qm);
         }
       }
-      const int any_rvo = __syncthreads_or(rvo ? 1 : 0);
+      __syncthreads();
       TICK(1);
-      if (any_rvo && !AB(1)) {
-        // ================= P1: squared centre distances of every (agent, other) pair (Agent::insertAgentNeighbor)
+      F2 v_orca = f2(0.f, 0.f);  // this lane's ORCA velocity (agent wave)
+      if (!AB(1)) {
+        // ================= P2: every (agent, other) pair: neighbour rank (ascending distSq, ties by index:
+        // Agent::insertAgentNeighbor) + ORCA half-plane
         const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
-#pragma unroll
-        for (int w = tid; w < n_items; w += NT) {
-          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-          const int j = w - ag * N;
-          if (!sh_q[ag]) continue;
-          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
-          float d2 = INFINITY;
-          if (j != aa) {
-            const F2 d = f2(sh_fpx[ag], sh_fpy[ag]) - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
-            d2 = dotf(d, d);
-            if (!(d2 < range_sq)) d2 = INFINITY;
-          }
-          dmat[j * CS + ag] = d2;
-        }
-        __syncthreads();
-        // ================= P2: neighbour rank (ascending distSq, ties by index) + ORCA half-plane
         const float inv_h = divf(1.0f, static_cast<float>(p.rvo_time_horizon));
-        const float ts = static_cast<float>(p.dt);
+        const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
         const float collab = static_cast<float>(p.rvo_collab_coeff);
+        const int n_live = sh_q3[ROW + 1];
+        const int n_orca = n_live * N;  // (querying agent, other) items
+        DUP(256)
 #pragma unroll
-        for (int w = tid; w < n_items; w += NT) {
-          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-          const int j = w - ag * N;
-          if (!sh_q[ag]) continue;
+        for (int base_ = 0, odd_ = 0; base_ < (NC ? n_items : n_orca); base_ += NT, odd_ ^= 1) {
+          const int w = base_ + (odd_ ? (NT - 1 - tid) : tid);
+          if (w >= n_orca) continue;
+          const int cag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
+          const int j = w - cag * N;
+          const int ag = sh_q[cag];
           const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
-          const float dj = dmat[j * CS + ag];
+          const F2 mpos = f2(sh_fpx[ag], sh_fpy[ag]);
+          float dj = INFINITY;
+          if (j != aa) {
+            const F2 d = mpos - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
+            dj = dotf(d, d);
+            if (!(dj < range_sq)) dj = INFINITY;
+          }
           int rank = 0, cnt = 0;
           for (int q = 0; q < N; ++q) {
-            const float dq = dmat[q * CS + ag];
+            const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
+            float dq = dotf(d, d);
+            dq = (q != aa && dq < range_sq) ? dq : INFINITY;
             rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
             cnt += static_cast<int>(dq < INFINITY);
           }
@@ -585,68 +592,141 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           if (j == aa) {
             sh_nb[ag] = n;
           } else if (dj < INFINITY && rank < n) {
-            Lmat[rank * CS + ag] = half_plane(f2(sh_fpx[ag], sh_fpy[ag]), f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
+            Lmat[rank * CS + ag] = half_plane(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
                                                f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
                                                sh_frad[eb + j], collab, inv_h, ts);
           }
         }
+        if (wave0 && rvo) {  // the preferred velocity (float64 sqrt + divide), while the other waves finish the pairs
+          const double vx = r.gx - r.px, vy = r.gy - r.py;
+          const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
+          sh_fprx[lane] = static_cast<float>(sc * vx);
+          sh_fpry[lane] = static_cast<float>(sc * vy);
+          sh_fms[lane] = static_cast<float>(r.ps);
+        }
         __syncthreads();
-      }
-
-      TICK(2);
-      // ================= A2a: the ORCA linear program.
-      //   N <= 16: solved by 16-lane groups of EVERY wave, one lane per half-plane (cagpu_grouplp.inc): linearProgram2
-      //            costs O(#violated lines) group steps instead of a serial O(n^2) walk through LDS, and the 4.6 % of
-      //            queries that fall through to linearProgram3 (94 % of the 60-agent tiles hold at least one) no
-      //            longer stall the other 59 lanes of a wave;
-      //   N  > 16: the same with one WAVE per agent (lane j = half-plane j, N - 1 <= 63): row reductions by DPP, the
-      //            four rows combined with two xor shuffles.
-      {
-        // one group per agent: 16 lanes while N <= 16 (four agents per wave side by side), the whole wave otherwise
-        auto solve = [&](auto gs_tag) {
-          constexpr int GS = decltype(gs_tag)::value;
-          constexpr int GROUPS = NT / GS;
-          if (any_rvo && !AB(2)) {
-            const int jl = tid & (GS - 1);
-            for (int agf = tid / GS; agf < tile_n; agf += GROUPS) {
-              if (!sh_q[agf]) continue;
-              const int nf = sh_nb[agf];
-              const bool valid = jl < nf;
-              const float4 ln = Lmat[(valid ? jl : 0) * CS + agf];
-              const F2 P = f2(ln.x, ln.y), D = f2(ln.z, ln.w);
-              const float ms = sh_fms[agf];
-              F2 v;
-              const int failf = lp2_group<GS>(valid, P, D, ms, f2(sh_fprx[agf], sh_fpry[agf]), false, v, jl, tid & 63);
-              if (jl == 0) {
-                sh_vrx[agf] = v.x;
-                sh_vry[agf] = v.y;
-                // infeasible (4.6 % of the queries at N = 10): queue the agent for the linearProgram3 pass below instead
-                // of solving it here, where it would stall the sibling groups of this wave for ~10 k cycles
-                if (failf != NOFAIL) sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = agf | (failf << 8);
-              }
+        TICK(2);
+        // ================= P2b: linearProgram1 of EVERY line i against the lines before it, one thread per (agent, i).
+        // The 1-D optimum on line i depends on the lines [0, i), the speed disc and the preferred velocity only -- not
+        // on the running result of linearProgram2 -- so all of them are computed side by side (min / max are exact and
+        // a 1-D programme is infeasible iff its final interval is empty), and linearProgram2 itself shrinks to the scan
+        // below: per line one violation test and one select.  Bit-identical to the incremental form.
+        // Items are line-major (w = i * n_live + c): the lanes of a wave hold (nearly) the same line index i, so the
+        // loop over the lines m < i runs to a wave-uniform bound instead of N - 2 for everybody.
+        const int n_lp1 = n_live * (N - 1);
+        const float inv_live = 1.0f / static_cast<float>(n_live > 0 ? n_live : 1);
+        DUP(512)
+        for (int base_ = 0; base_ < n_lp1; base_ += NT) {
+          const int w = base_ + tid;
+          const int w_hi = (base_ + (tid | 63) < n_lp1) ? base_ + (tid | 63) : n_lp1 - 1;  // the wave's last item
+          const int i_hi = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(w_hi) + 0.5f) * inv_live));
+          const bool item = w < n_lp1;
+          const int i = item ? static_cast<int>((static_cast<float>(w) + 0.5f) * inv_live) : 0;
+          const int ag = sh_q[item ? w - i * n_live : 0];
+          const bool live = item && i < sh_nb[ag];
+          const float4 li = Lmat[i * CS + ag];
+          const F2 Pi = f2(li.x, li.y), Di = f2(li.z, li.w);
+          const float radius = sh_fms[ag];
+          const F2 opt = f2(sh_fprx[ag], sh_fpry[ag]);
+          const float dp = dotf(Pi, Di);
+          const float disc = sqf(dp) + sqf(radius) - dotf(Pi, Pi);
+          bool ok = !(disc < 0.0f);
+          const float sd = sqrtf_rn(ok ? disc : 0.0f);
+          float t_lo = -dp - sd;
+          float t_hi = -dp + sd;
+          if (base_ + (tid & ~63) < n_lp1) {  // wave-uniform: this wave has items in this round
+#pragma unroll 4
+            for (int m = 0; m < i_hi; ++m) {
+              const bool use = m < i;
+              const float4 lm = Lmat[(use ? m : 0) * CS + ag];
+              const F2 Pm = f2(lm.x, lm.y), Dm = f2(lm.z, lm.w);
+              const float den = detf(Di, Dm);
+              const float num = detf(Dm, Pi - Pm);
+              const bool par = fabsf(den) <= kRvoEps;
+              ok = ok && !(use && par && num < 0.0f);
+              const float tt = divf(num, par ? 1.0f : den);
+              const float c_hi = (use && !par && den >= 0.0f) ? tt : INFINITY;
+              const float c_lo = (use && !par && den < 0.0f) ? tt : -INFINITY;
+              t_hi = (c_hi < t_hi) ? c_hi : t_hi;
+              t_lo = (t_lo < c_lo) ? c_lo : t_lo;
             }
           }
-          __syncthreads();
-          const int n3 = any_rvo ? sh_q3[0] : 0;
-          if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+          ok = ok && !(t_lo > t_hi);
+          const float t = dotf(Di, opt - Pi);
+          const float tc = (t < t_lo) ? t_lo : ((t > t_hi) ? t_hi : t);
+          const F2 res = Pi + tc * Di;
+          if (live) {
+            Rmat[i * CS + ag] = make_float2(res.x, res.y);
+            okmat[i * CS + ag] = ok ? 1 : 0;
+          }
+        }
+        __syncthreads();
+        TICK(12);
+        // ================= linearProgram2 = a scan over the lines, one lane per agent (agent wave); infeasible
+        // programmes (4.6 % of the queries at N = 10) are queued for the cooperative linearProgram3 pass
+        int failf = NOFAIL;
+        if (wave0 && rvo) {
+          const int n = sh_nb[lane];
+          const float radius = sh_fms[lane];
+          const F2 opt = f2(sh_fprx[lane], sh_fpry[lane]);
+          F2 res = opt;
+          if (dotf(opt, opt) > sqf(radius)) res = radius * unitf(opt);
+#pragma unroll
+          for (int i = 0; i < (NC ? NC - 1 : n); ++i) {
+            // loads do not depend on the running result: all of them can be in flight before the select chain starts
+            const float4 li = Lmat[i * CS + lane];
+            const float2 ri = Rmat[i * CS + lane];
+            const int oki = okmat[i * CS + lane];
+            const bool viol = (i < n) && (failf == NOFAIL) && (detf(f2(li.z, li.w), f2(li.x, li.y) - res) > 0.0f);
+            res.x = (viol && oki) ? ri.x : res.x;
+            res.y = (viol && oki) ? ri.y : res.y;
+            failf = (viol && !oki) ? i : failf;
+          }
+          v_orca = res;
+          if (failf != NOFAIL) {
+            sh_vrx[lane] = res.x;
+            sh_vry[lane] = res.y;
+            sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = lane | (failf << 8);
+          }
+        }
+        __syncthreads();
+        // ================= linearProgram3 for the queued agents.  N <= 10 (at most 9 lines): one WAVE per agent, all pair
+        // intersections of the embedded linearProgram2 in one step (lp3_wave8); otherwise one 16-lane group per agent
+        // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
+        const int n3 = sh_q3[0];
+        if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+          auto solve3 = [&](auto gs_tag) {
+            constexpr int GS = decltype(gs_tag)::value;
+            constexpr int GROUPS = NT / GS;
             // queue entry k goes to wave k % (number of waves) first: infeasible agents are solved side by side
             const int jl = tid & (GS - 1), g = tid / GS;
             constexpr int GPW = 64 / GS;  // groups per wave
             for (int q3 = (g % GPW) * (NT / 64) + (g / GPW); q3 < n3; q3 += GROUPS) {
-              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, failf = ent >> 8;
+              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = ent >> 8;
               const int nf = sh_nb[agf];
               const float4 ln = Lmat[((jl < nf) ? jl : 0) * CS + agf];
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
-              lp3_group<GS>(nf, failf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
+              lp3_group<GS>(nf, ff, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[agf], v, jl, tid & 63);
               if (jl == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
             }
-            __syncthreads();
+          };
+          if (N <= 10) {
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            for (int q3 = wv; q3 < n3; q3 += NT / 64) {
+              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = ent >> 8;
+              F2 v = f2(sh_vrx[agf], sh_vry[agf]);
+              lp3_wave8(Lmat + agf, CS, sh_nb[agf], ff, sh_fms[agf], v, tid & 63, sh_x3 + 8 * wv);
+              if ((tid & 63) == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
+            }
+          } else if (N <= G16) {
+            solve3(std::integral_constant<int, 16>{});
+          } else {
+            solve3(std::integral_constant<int, 64>{});
           }
-        };
-        if (N <= G16) solve(std::integral_constant<int, 16>{});
-        else solve(std::integral_constant<int, 64>{});
+          __syncthreads();
+          if (failf != NOFAIL) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
+        }
       }
-      TICK(12);
       TICK(3);
       // ================= A2c: policy post-processing (env.py:305-323) and move (agent.py:192-241), one lane per agent
       TICK(0);
@@ -654,8 +734,8 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         double spd = 0.0, dh = 0.0;
         if (query) {
           if (pol == CA_POL_RVO) {
-            const float ts = static_cast<float>(p.dt);
-            const F2 v = f2(sh_vrx[lane], sh_vry[lane]);
+            const float ts = static_cast<float>(p.rvo_dt);
+            const F2 v = v_orca;
             // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
             const float npx = sh_fpx[lane] + v.x * ts, npy = sh_fpy[lane] + v.y * ts;
             const double dpx = static_cast<double>(npx) - r.px, dpy = static_cast<double>(npy) - r.py;
@@ -665,7 +745,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
             dh = wrap_pi(nh - r.heading);
             TICK(14);
-            spd = (1.0 / p.dt) * sqrt(dpx * dpx + dpy * dpy);
+            spd = (1.0 / p.rvo_dt) * sqrt(dpx * dpx + dpy * dpy);  // RVOPolicy.py:106
             if (fabs(dh) > kPi / 6) {
               dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
               spd = 0.0;
@@ -761,8 +841,10 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
 
       // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
       //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
+      DUP(2048)
 #pragma unroll
-      for (int w = tid; w < n_items && !AB(32); w += NT) {
+      FOR_PAIR_ITEMS(w) {
+        if (AB(32)) continue;
         const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
         const int j = w - ag * N;
         if (!sh_sense[ag]) continue;
@@ -793,54 +875,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       __syncthreads();
 
       TICK(7);
-      // ---- A3 (wave 0): rewards + collision flag (env.py:394-456), observation scalars
-      if (wave0 && active) {
-        if (k.mode == MODE_STEP && pass == 0) {
-          double nearest = INFINITY;
-          for (int j = 0; j < N; ++j) {
-            const double g = gmat[j * CS + lane];
-            nearest = (g < nearest) ? g : nearest;
-          }
-          const bool coll = nearest <= 0.0;  // some d <= r_i + r_j  <=>  min(d - (r_i + r_j)) <= 0
-          double rw = p.reward_time_step;
-          if (r.flags & CA_AT_GOAL) {
-            if (!(r.flags & CA_WAS_AT_GOAL)) rw = p.reward_at_goal;
-          } else if (!(r.flags & CA_WAS_IN_COLLISION)) {
-            if (coll) {
-              rw = p.reward_collision;
-              r.flags |= CA_IN_COLLISION;
-            } else if (hits_wall(k.map, r.px, r.py, r.rad)) {  // env.py:425-429, :494-506 (same reward value)
-              rw = p.reward_collision;
-              r.flags |= CA_IN_COLLISION;
-            } else {
-              if (nearest <= p.getting_close_range) rw = -0.1 - nearest / 2.0;
-              if (fabs(static_cast<double>(r.act1)) > p.wiggly_threshold) rw += p.reward_wiggly;
-            }
-          }
-          rw = fmin(fmax(rw, p.reward_min), p.reward_max);
-          r.epr += rw;
-          reward = static_cast<float>(rw);
-          const bool d = (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) != 0;
-          if (d) r.flags |= CA_DONE; else r.flags &= ~static_cast<uint32_t>(CA_DONE);
-          sh_flag[lane] = r.flags;
-          sh_r0[lane] = r.epr;
-          sh_r1[lane] = r.t;
-          sh_r2[lane] = r.t - r.slt;
-        }
-        if (do_sense) {
-          float* row = STAGE ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
-          row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
-          row[2] = static_cast<float>(eg.dist);
-          row[3] = static_cast<float>(eg.heading_ego);
-          row[4] = static_cast<float>(r.ps);
-          row[5] = static_cast<float>(r.rad);
-        }
-      }
-
-      TICK(8);
       // ---- P4: rank the candidates of every agent and emit its rows (OtherAgentsStatesSensor.py:20-55,109-143)
+      DUP(4096)
 #pragma unroll
-      for (int w = tid; w < n_items && !AB(64); w += NT) {
+      FOR_PAIR_ITEMS(w) {
+        if (AB(64)) continue;
         const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
         const int j = w - ag * N;
         if (!sh_sense[ag]) continue;
@@ -906,7 +945,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       }
       if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
         __syncthreads();
-        for (int w = tid; w < n_items; w += NT) {
+        FOR_PAIR_ITEMS(w) {
           const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
           const int j = w - ag * N;
           if (!sh_sense[ag]) continue;
@@ -938,6 +977,52 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           o7[6] = d2mat[j * CS + ag];
         }
       }
+      // ---- A3 (wave 0, while the other waves finish the pair items of P4): rewards + collision flag (env.py:394-456),
+      // observation scalars
+      if (wave0 && active) {
+        if (k.mode == MODE_STEP && pass == 0) {
+          double nearest = INFINITY;
+          for (int j = 0; j < N; ++j) {
+            const double g = gmat[j * CS + lane];
+            nearest = (g < nearest) ? g : nearest;
+          }
+          const bool coll = nearest <= 0.0;  // some d <= r_i + r_j  <=>  min(d - (r_i + r_j)) <= 0
+          double rw = p.reward_time_step;
+          if (r.flags & CA_AT_GOAL) {
+            if (!(r.flags & CA_WAS_AT_GOAL)) rw = p.reward_at_goal;
+          } else if (!(r.flags & CA_WAS_IN_COLLISION)) {
+            if (coll) {
+              rw = p.reward_collision;
+              r.flags |= CA_IN_COLLISION;
+            } else if (hits_wall(k.map, r.px, r.py, r.rad)) {  // env.py:425-429, :494-506
+              rw = p.reward_collision_wall;
+              r.flags |= CA_IN_COLLISION;
+            } else {
+              if (nearest <= p.getting_close_range) rw = -0.1 - nearest / 2.0;
+              if (fabs(static_cast<double>(r.act1)) > p.wiggly_threshold) rw += p.reward_wiggly;
+            }
+          }
+          rw = fmin(fmax(rw, p.reward_min), p.reward_max);
+          r.epr += rw;
+          reward = static_cast<float>(rw);
+          const bool d = (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) != 0;
+          if (d) r.flags |= CA_DONE; else r.flags &= ~static_cast<uint32_t>(CA_DONE);
+          sh_flag[lane] = r.flags;
+          sh_r0[lane] = r.epr;
+          sh_r1[lane] = r.t;
+          sh_r2[lane] = r.t - r.slt;
+        }
+        if (do_sense) {
+          float* row = STAGE ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
+          row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
+          row[2] = static_cast<float>(eg.dist);
+          row[3] = static_cast<float>(eg.heading_ego);
+          row[4] = static_cast<float>(r.ps);
+          row[5] = static_cast<float>(r.rad);
+        }
+      }
+
+      TICK(8);
       __syncthreads();
 
       TICK(9);
@@ -1143,7 +1228,7 @@ int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   if (p->sort_mode < CA_SORT_CLOSEST_FIRST || p->sort_mode > CA_SORT_TIME_TO_IMPACT)
     return fail(CA_EINVAL, "cagpu: unknown sort_mode (OtherAgentsStatesSensor.py:52 raises ValueError)%s");
   if (p->game_over_mode < 0 || p->game_over_mode > 2) return fail(CA_EINVAL, "cagpu: bad game_over_mode%s");
-  if (!(p->dt > 0.0)) return fail(CA_EINVAL, "cagpu: dt must be > 0%s");
+  if (!(p->dt > 0.0) || !(p->rvo_dt > 0.0)) return fail(CA_EINVAL, "cagpu: dt and rvo_dt must be > 0%s");
   if (!o->obs || !o->rewards || !o->done || !o->game_over) return fail(CA_EINVAL, "cagpu: NULL output pointer%s");
   const void* ptrs[] = {s->pos_x, s->pos_y, s->vel_x, s->vel_y, s->heading, s->goal_x, s->goal_y, s->radius,
                         s->pref_speed, s->time_remaining, s->t, s->slt, s->ep_reward, s->last_action, s->flags,
@@ -1171,7 +1256,7 @@ int device_cus() {  // CU count of the current device, cached per device id
 }
 
 struct Knobs {  // experiment overrides (-DCAGPU_ABLATE builds only); -1 / 0 = not set
-  int tile = 0, nt = 0, stage = -1, no_nc = 0, rollout_fused = 0, aw_shift = -2;
+  int tile = 0, nt = 0, stage = -1, no_nc = 0, rollout_fused = 0;
 };
 const Knobs& knobs() {
 #if defined(CAGPU_ABLATE) || defined(CAGPU_KNOBS)
@@ -1183,7 +1268,6 @@ const Knobs& knobs() {
     if (std::getenv("CAGPU_NOSTAGE")) q.stage = 0;
     if (std::getenv("CAGPU_NO_NC")) q.no_nc = 1;
     if (std::getenv("CAGPU_ROLLOUT_FUSED")) q.rollout_fused = 1;
-    if (const char* e = std::getenv("CAGPU_AW_SHIFT")) q.aw_shift = std::atoi(e);
     return q;
   }();
   return kn;
@@ -1210,9 +1294,9 @@ int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   }
   const int tile_envs = k.tile_envs;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + tile_envs - 1) / tile_envs);
-  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_kernel<%d, %s, %d, %s, %s, %d> grid=%u lds=%zu tile_envs=%d aw_shift=%d",
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_kernel<%d, %s, %d, %s, %s, %d> grid=%u lds=%zu tile_envs=%d",
                 NT, STAGE ? "true" : "false", NC, MULTI ? "true" : "false", RO ? "true" : "false", TE, grid, total,
-                tile_envs, k.aw_shift);
+                tile_envs);
   hipLaunchKernelGGL((ca_kernel<NT, STAGE, NC, MULTI, RO, TE>), dim3(grid), dim3(NT), total, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
@@ -1239,7 +1323,11 @@ int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
       if (k.tile_envs == 4) return launch_main3<NT, STAGE, 10, 4>(k, total, st);
     }
   }
+#ifdef CAGPU_FAST  // scratch builds: only the N = 10 instantiations are compiled
+  return fail(CA_EUNSUPPORTED, "cagpu: CAGPU_FAST experiment build supports num_agents == 10 only%s");
+#else
   return launch_main3<NT, STAGE, 0>(k, total, st);
+#endif
 }
 
 template <int NT>
@@ -1262,6 +1350,9 @@ int launch_main(const KArgs& k, hipStream_t st) {
   const long resident_staged = (per_cu < 3 ? per_cu : 3) * n_cu;
   bool crowded = wgs > resident_staged;
   if (knobs().stage == 1) crowded = false;
+#ifdef CAGPU_FAST
+  crowded = true;
+#endif
   if (total > 64 * 1024 || crowded || knobs().stage == 0) {  // give up the staging area
     un_sense = lds_sense_bytes(N, W, 0, tti, cs);
     stage = false;
@@ -1277,12 +1368,20 @@ int launch_main(const KArgs& k, hipStream_t st) {
     KArgs k1 = k;
     k1.n_steps = 1;
     for (int i = 0; i < k.n_steps; ++i) {
+#ifdef CAGPU_FAST
+      const int rc = launch_main2<256, false>(k1, total, st);
+#else
       const int rc = stage ? launch_main2<256, true>(k1, total, st) : launch_main2<256, false>(k1, total, st);
+#endif
       if (rc) return rc;
     }
     return CA_OK;
   }
+#ifdef CAGPU_FAST
+  return launch_main2<NT, false>(k, total, st);
+#else
   return stage ? launch_main2<NT, true>(k, total, st) : launch_main2<NT, false>(k, total, st);
+#endif
 }
 
 // Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
@@ -1302,14 +1401,16 @@ int launch_any(const KArgs& k0, void* stream) {
     if ((static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * device_cus()) k.tile_envs = 4;
   }
   if (knobs().tile >= 1 && knobs().tile < k.tile_envs) k.tile_envs = knobs().tile;
-  k.aw_shift = AW_SHIFT_DEFAULT;
-  if (knobs().aw_shift > -2) k.aw_shift = knobs().aw_shift;
   // N > 32: the tile is a single env whose N^2 pair items (and N wave-wide linear programs) keep 8 waves busy, and
   // its LDS footprint allows only one or two workgroups per CU anyway
   int nt = (N > 32) ? 512 : 256;
   if (knobs().nt) nt = knobs().nt;
+#ifdef CAGPU_FAST
+  return launch_main<256>(k, st);
+#else
   if (nt <= 256) return launch_main<256>(k, st);
   return launch_main<512>(k, st);
+#endif
 }
 
 int pick_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : 256); }

@@ -258,6 +258,7 @@ class CollisionAvoidanceEnv(Env):
         p.dt, p.near_goal_threshold, p.max_time_ratio = Config.DT, Config.NEAR_GOAL_THRESHOLD, Config.MAX_TIME_RATIO
         p.getting_close_range, p.sensing_horizon = Config.GETTING_CLOSE_RANGE, Config.SENSING_HORIZON
         p.reward_at_goal, p.reward_collision = self.reward_at_goal, self.reward_collision_with_agent
+        p.reward_collision_wall, p.rvo_dt = self.reward_collision_with_wall, Config.DT   # RVOPolicy.py:13
         p.reward_time_step, p.reward_wiggly = self.reward_time_step, self.reward_wiggly_behavior
         p.wiggly_threshold = self.wiggly_behavior_threshold
         p.reward_min, p.reward_max = self.min_possible_reward, self.max_possible_reward

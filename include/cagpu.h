@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 1
+#define CAGPU_VERSION 2
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -86,6 +86,9 @@ typedef struct CaParams {
   double reward_min, reward_max; /* np.clip bounds (collision_avoidance_env.py:589-599) */
   double rvo_time_horizon, rvo_collab_coeff;
   double max_heading_change; /* env-wide pi/3 (collision_avoidance_env.py:87), LearningPolicy.py:30 */
+  double reward_collision_wall; /* REWARD_COLLISION_WITH_WALL (config.py:33; collision_avoidance_env.py:425-429) */
+  double rvo_dt;             /* RVOPolicy.dt = Config.DT (RVOPolicy.py:13): rvo2's timeStep and the 1/dt of the speed
+                                read-back (:26, :106) -- NOT the dt of this step() call, which only the dynamics see */
 } CaParams;
 
 /* Device pointers to the simulator state; [E*N] unless noted. */

@@ -268,7 +268,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
           }
           have_bodies = true;
         }
-        const float ts = static_cast<float>(p.dt);
+        const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
         const orca_ref::Vec v = orca_ref::new_velocity(body.data(), N, a, static_cast<float>(p.sensing_horizon),
                                                        static_cast<size_t>(p.rvo_max_neighbors),
                                                        static_cast<float>(p.rvo_time_horizon), ts);
@@ -278,7 +278,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
         const double ang = std::atan2(dpy, dpx) - 0.0;                    // :100-101
         const double nh = pymod(ang, kTwoPi);                             // :102
         dh = wrap(nh - s.heading[i]);                                     // :103
-        spd = (1.0 / p.dt) * std::sqrt(dpx * dpx + dpy * dpy);            // :106
+        spd = (1.0 / p.rvo_dt) * std::sqrt(dpx * dpx + dpy * dpy);        // :106
         if (std::fabs(dh) > kPi / 6) {                                    // :109-111
           dh = sgn(dh) * (kPi / 6);
           spd = 0.0;
@@ -383,7 +383,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
         r = p.reward_collision;
         f |= ORC_IN_COLLISION;
       } else if (map && hits_wall(*map, s.pos_x[i], s.pos_y[i], s.radius[i])) {  // env.py:425-429
-        r = p.reward_collision;  // REWARD_COLLISION_WITH_WALL has the same value (config.py:32-33)
+        r = p.reward_collision_wall;  // config.py:33
         f |= ORC_IN_COLLISION;
       } else {
         if (nearest[a] <= p.getting_close_range) r = -0.1 - nearest[a] / 2.0;

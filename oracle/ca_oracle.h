@@ -48,6 +48,8 @@ typedef struct {
   double reward_min, reward_max; /* np.clip bounds, env.py:589-599 */
   double rvo_time_horizon, rvo_collab_coeff;
   double max_heading_change; /* env-wide pi/3, env.py:87, used by LearningPolicy.py:30 */
+  double reward_collision_wall; /* config.py:33, env.py:425-429 */
+  double rvo_dt;             /* RVOPolicy.py:13: Config.DT (timeStep of rvo2 and the 1/dt of :106) */
 } OrcParams;
 
 /* SoA state, index e*num_agents + a */

@@ -33,7 +33,8 @@ class OrcParams(C.Structure):
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
-                                          "rvo_time_horizon", "rvo_collab_coeff", "max_heading_change")]
+                                          "rvo_time_horizon", "rvo_collab_coeff", "max_heading_change",
+                                          "reward_collision_wall", "rvo_dt")]
 
 
 _STATE_F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
@@ -96,6 +97,7 @@ def default_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.
     p.reward_min, p.reward_max = -0.25, 1.0
     p.rvo_time_horizon, p.rvo_collab_coeff = 5.0, 0.5
     p.max_heading_change = math.pi / 3
+    p.reward_collision_wall, p.rvo_dt = -0.25, dt
     return p
 
 

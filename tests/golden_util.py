@@ -61,5 +61,5 @@ def apply_constants(meta, *params):
             if k in meta:
                 setattr(p, field, float(meta[k]))
         # collision_avoidance_env.py:589-599: clip bounds = min / max of the possible reward values
-        vals = [p.reward_at_goal, p.reward_collision, p.reward_time_step, p.reward_collision, p.reward_wiggly]
+        vals = [p.reward_at_goal, p.reward_collision, p.reward_time_step, p.reward_collision_wall, p.reward_wiggly]
         p.reward_min, p.reward_max = min(vals), max(vals)

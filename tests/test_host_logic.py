@@ -29,12 +29,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.cagpu_version.restype = ctypes.c_int
-    assert lib.cagpu_version() == 1   # host-only call, no GPU needed
+    assert lib.cagpu_version() == 2   # host-only call, no GPU needed
 
 
 def test_ctypes_structs_match_header_layout():
     from gym_collision_avoidance_amd import _native as nat
-    assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 15 * 8
+    assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 17 * 8
     assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
     assert ctypes.sizeof(nat.CaAutoReset) == 40 and nat.CaAutoReset.reset_obs.offset == 32
     assert nat.CaParams.dt.offset == 32
