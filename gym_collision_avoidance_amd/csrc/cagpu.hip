@@ -60,6 +60,7 @@ struct KArgs {
   int32_t n_steps, mode, stage_obs;
   int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
   int32_t col_stride; // columns of the per-(agent, slot) LDS tiles: ROW, or N for single-env tiles (N > 32)
+  double inv_rvo_dt;  // 1 / p.rvo_dt (RVOPolicy.py:106), divided once on the host
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -91,6 +92,36 @@ __device__ __forceinline__ double wrap_pi(double a) {  // util.py:141-146 ([-pi,
     for (int it = 0; it < 4096 && a < -kPi; ++it) a += kTwoPi;
   }
   return a;
+}
+
+// sin and cos of a heading in [-pi, pi] (UnicycleDynamics.py:29-32): Cody-Waite reduction by pi/2 (two-part constant,
+// |k| <= 2) and the fdlibm kernel polynomials -- ~45 instructions where the general-range libm sincos needs ~150.
+// Accuracy (checked against long-double libm on 2e7 arguments): <= 1 ulp, except within 1e-11 of a multiple of pi/2
+// where the ABSOLUTE error stays below 1e-26 (the result itself is ~1e-12 there); 97.6 % of the results are
+// bit-identical to glibc's.  The products these feed are positions of order 1..10 m.
+__device__ __forceinline__ void sincos_heading(double x, double& s, double& c) {
+  const double kf = rint(x * 6.36619772367581382433e-01);
+  const int k = static_cast<int>(kf);
+  const double r = __builtin_fma(-kf, 1.57079632673412561417e+00, x);  // first 33 bits of pi/2: exact product
+  const double w = kf * 6.07710050650619224932e-11;                     // pi/2 - the 33 bits
+  const double y = r - w;
+  const double yt = (r - y) - w;
+  const double z = y * y;
+  const double v = z * y;
+  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                    -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                    8.33333333332248946124e-03);
+  const double sn = y - ((z * (0.5 * yt - v * rs) - yt) - v * -1.66666666666666324348e-01);
+  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                    -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                    2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double ww = 1.0 - hz;
+  const double cs = ww + (((1.0 - ww) - hz) + (z * rc - y * yt));
+  const bool swap = (k & 1) != 0;
+  const double s0 = swap ? cs : sn, c0 = swap ? sn : cs;
+  s = (k & 2) ? -s0 : s0;
+  c = (((k + 1) & 2) != 0) ? -c0 : c0;
 }
 
 // ---------------------------------------------------------------- ORCA (RVO2 algorithm, C float)
@@ -559,6 +590,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         // ================= P2: every (agent, other) pair: neighbour rank (ascending distSq, ties by index:
         // Agent::insertAgentNeighbor) + ORCA half-plane
         const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
+        const bool unlimited = !(range_sq < INFINITY);
         const float inv_h = divf(1.0f, static_cast<float>(p.rvo_time_horizon));
         const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
         const float collab = static_cast<float>(p.rvo_collab_coeff);
@@ -578,15 +610,25 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           if (j != aa) {
             const F2 d = mpos - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
             dj = dotf(d, d);
-            if (!(dj < range_sq)) dj = INFINITY;
+            if (!unlimited && !(dj < range_sq)) dj = INFINITY;
           }
-          int rank = 0, cnt = 0;
-          for (int q = 0; q < N; ++q) {
-            const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
-            float dq = dotf(d, d);
-            dq = (q != aa && dq < range_sq) ? dq : INFINITY;
-            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
-            cnt += static_cast<int>(dq < INFINITY);
+          int rank = 0, cnt = N - 1;
+          if (unlimited) {  // neighborDist = inf (Config.SENSING_HORIZON, RVOPolicy.py:27): every other agent is a neighbour
+            for (int q = 0; q < N; ++q) {
+              const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
+              float dq = dotf(d, d);
+              dq = (q != aa) ? dq : INFINITY;
+              rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
+            }
+          } else {
+            cnt = 0;
+            for (int q = 0; q < N; ++q) {
+              const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
+              float dq = dotf(d, d);
+              dq = (q != aa && dq < range_sq) ? dq : INFINITY;
+              rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));
+              cnt += static_cast<int>(dq < INFINITY);
+            }
           }
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (j == aa) {
@@ -673,14 +715,18 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           if (dotf(opt, opt) > sqf(radius)) res = radius * unitf(opt);
 #pragma unroll
           for (int i = 0; i < (NC ? NC - 1 : n); ++i) {
-            // loads do not depend on the running result: all of them can be in flight before the select chain starts
+            // The loads do not depend on the running result, so all of them can be in flight before the select chain
+            // starts -- provided the tests stay branch-free: the conditions are combined as integers (written with &&
+            // the compiler guards every load with its own branch + wait, one LDS round trip per line).
             const float4 li = Lmat[i * CS + lane];
             const float2 ri = Rmat[i * CS + lane];
             const int oki = okmat[i * CS + lane];
-            const bool viol = (i < n) && (failf == NOFAIL) && (detf(f2(li.z, li.w), f2(li.x, li.y) - res) > 0.0f);
-            res.x = (viol && oki) ? ri.x : res.x;
-            res.y = (viol && oki) ? ri.y : res.y;
-            failf = (viol && !oki) ? i : failf;
+            const float dt = detf(f2(li.z, li.w), f2(li.x, li.y) - res);
+            const int hit = static_cast<int>(i < n) & static_cast<int>(failf == NOFAIL) & static_cast<int>(dt > 0.0f);
+            const int take = hit & (oki != 0 ? 1 : 0);
+            res.x = take ? ri.x : res.x;
+            res.y = take ? ri.y : res.y;
+            failf = (hit & (take ^ 1)) ? i : failf;
           }
           v_orca = res;
           if (failf != NOFAIL) {
@@ -690,6 +736,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           }
         }
         __syncthreads();
+        TICK(15);
         // ================= linearProgram3 for the queued agents.  N <= 10 (at most 9 lines): one WAVE per agent, all pair
         // intersections of the embedded linearProgram2 in one step (lp3_wave8); otherwise one 16-lane group per agent
         // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
@@ -739,13 +786,12 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             // Agent::update: float position += v * timeStep; RVOPolicy.py:96-111
             const float npx = sh_fpx[lane] + v.x * ts, npy = sh_fpy[lane] + v.y * ts;
             const double dpx = static_cast<double>(npx) - r.px, dpy = static_cast<double>(npy) - r.py;
-            TICK(15);
             const double ang = AB(4) ? dpy : atan2(dpy, dpx);
             TICK(13);
             const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
             dh = wrap_pi(nh - r.heading);
             TICK(14);
-            spd = (1.0 / p.rvo_dt) * sqrt(dpx * dpx + dpy * dpy);  // RVOPolicy.py:106
+            spd = k.inv_rvo_dt * sqrt(dpx * dpx + dpy * dpy);  // RVOPolicy.py:106: 1/self.dt * norm
             if (fabs(dh) > kPi / 6) {
               dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
               spd = 0.0;
@@ -800,7 +846,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
                 nh = wrap_pi(a1 + r.heading);  // UnicycleDynamics.py:28
               }
               double sn, cs;
-              if (AB(8)) { sn = nh; cs = 1.0 - nh; } else sincos(nh, &sn, &cs);
+              if (AB(8)) { sn = nh; cs = 1.0 - nh; } else sincos_heading(nh, sn, cs);
               r.px += a0 * cs * p.dt;
               r.py += a0 * sn * p.dt;
               r.vx = a0 * cs;
@@ -841,6 +887,64 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
 
       // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
       //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
+      if (NC != 0 && p.sort_mode != CA_SORT_TIME_TO_IMPACT) {
+        // N compiled in: one item per UNORDERED pair {a, b} -- the float64 square root, the collision gap and the
+        // horizon test are the same for both directions; only d - r_host - r_other (operand order) and p_orth (the
+        // host's frame) are direction-specific.  Per env: the pairs (a, a + s mod N) for s = 1 .. (N-1)/2, for even N
+        // the N/2 antipodal pairs, then N self entries: N (N + 1) / 2 items, 220 per 4-env tile = ONE round of 256.
+        constexpr int NN = NC ? NC : 2, HALF = (NN - 1) / 2, PE = NN * (NN + 1) / 2;
+        const int n_un = tile_envs * PE;
+        DUP(2048)
+#pragma unroll
+        FOR_ITEMS_UPTO(w, n_un) {
+          if (AB(32)) continue;
+          const int le2 = static_cast<int>((static_cast<float>(w) + 0.5f) * (1.0f / static_cast<float>(PE)));
+          const int u = w - le2 * PE, eb = le2 * NN;
+          if (!sh_sense[eb]) continue;  // sensing is decided per env
+          if (u >= PE - NN) {  // self entry: never sensed, no gap
+            const int a1 = u - (PE - NN);
+            kmat[a1 * CS + eb + a1] = KEY_NONE;
+            omat[a1 * CS + eb + a1] = 0.0;
+            d2mat[a1 * CS + eb + a1] = 0.f;
+            gmat[a1 * CS + eb + a1] = INFINITY;
+            continue;
+          }
+          int a1, b1;
+          if (u < NN * HALF) {
+            const int sft = static_cast<int>((static_cast<float>(u) + 0.5f) * (1.0f / static_cast<float>(NN)));
+            a1 = u - sft * NN;
+            b1 = a1 + sft + 1;
+            b1 -= (b1 >= NN) ? NN : 0;
+          } else {
+            a1 = u - NN * HALF;
+            b1 = a1 + NN / 2;
+          }
+          const int ga = eb + a1, gb = eb + b1;
+          const double ax = sh_px[ga], ay = sh_py[ga], ar = sh_rad[ga];
+          const double bx = sh_px[gb], by = sh_py[gb], br = sh_rad[gb];
+          const double rx = bx - ax, ry = by - ay;  // other - host for host a; exactly negated for host b
+          const double d = sqrt(rx * rx + ry * ry);
+          int key_ab = KEY_NONE, key_ba = KEY_NONE;
+          double po_ab = 0.0, po_ba = 0.0, d2_ab = 0.0, d2_ba = 0.0;
+          if (!(d > p.sensing_horizon)) {
+            d2_ab = d - ar - br;
+            d2_ba = d - br - ar;
+            // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100 (an integer: exact as int32)
+            key_ab = static_cast<int>(fmin(fmax(rint(d2_ab * 100.0), -2.0e9), 2.0e9));
+            key_ba = static_cast<int>(fmin(fmax(rint(d2_ba * 100.0), -2.0e9), 2.0e9));
+            po_ab = rx * (-sh_pry[ga]) + ry * sh_prx[ga];
+            po_ba = (-rx) * (-sh_pry[gb]) + (-ry) * sh_prx[gb];
+          }
+          kmat[b1 * CS + ga] = key_ab;
+          omat[b1 * CS + ga] = po_ab;
+          d2mat[b1 * CS + ga] = static_cast<float>(d2_ab);
+          gmat[b1 * CS + ga] = d - (ar + br);
+          kmat[a1 * CS + gb] = key_ba;
+          omat[a1 * CS + gb] = po_ba;
+          d2mat[a1 * CS + gb] = static_cast<float>(d2_ba);
+          gmat[a1 * CS + gb] = d - (br + ar);
+        }
+      } else {
       DUP(2048)
 #pragma unroll
       FOR_PAIR_ITEMS(w) {
@@ -872,6 +976,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         d2mat[j * CS + ag] = static_cast<float>(d2o);
         gmat[j * CS + ag] = gap;
       }
+      }
       __syncthreads();
 
       TICK(7);
@@ -902,18 +1007,27 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             cnt += static_cast<int>(vq);
           }
         } else {
-          // branch-free on purpose: both keys are loaded unconditionally and the lexicographic (key, p_orth, index)
-          // test is combined with bitwise operators, so the unrolled loop is 2 LDS reads + 4 compares per candidate
-          // with one wait for all of them (the short-circuit form compiled to a chain of dependent LDS round trips
-          // and ~10 taken branches per item)
+          // Pass 1 ranks by the distance bucket alone (one 4-byte key per candidate, branch-free).  Two candidates of
+          // an agent share a 1 cm bucket in a few per cent of the rows only: the (p_orth, index) tie-break -- an 8-byte
+          // load and two float64 compares per candidate -- runs as a second pass in the waves that hold such a row.
+          int same = 0;
           for (int q = 0; q < N; ++q) {
             const int kq = kmat[q * CS + ag];
-            const double oq = omat[q * CS + ag];
-            const int before = static_cast<int>(kq < kj) |
-                               (static_cast<int>(kq == kj) &
-                                (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j))));
-            rank += before;
-            cnt += static_cast<int>(kq != KEY_NONE);
+            rank += static_cast<int>(kq < kj);
+            same += static_cast<int>(kq == kj);
+          }
+          if (__any(same > 1)) {  // (a key always equals itself)
+            for (int q = 0; q < N; ++q) {
+              const int kq = kmat[q * CS + ag];
+              const double oq = omat[q * CS + ag];
+              rank += static_cast<int>(kq == kj) &
+                      (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j)));
+            }
+          }
+          if (p.sensing_horizon < INFINITY) {
+            for (int q = 0; q < N; ++q) cnt += static_cast<int>(kmat[q * CS + ag] != KEY_NONE);
+          } else {
+            cnt = N - 1;  // every other agent of the env is sensed
           }
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
@@ -1474,6 +1588,7 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
     k.map = *map;
   }
   k.n_steps = n_steps; k.mode = MODE_STEP;
+  k.inv_rvo_dt = 1.0 / p->rvo_dt;
 #ifdef CAGPU_ABLATE
   if (const char* ab = std::getenv("CAGPU_ABLATE")) k.ablate = std::atoi(ab);
 #endif

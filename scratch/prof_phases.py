@@ -12,11 +12,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gym_collision_avoidance_amd import _native as nat, core  # noqa: E402
 
-SLOTS = {0: "step entry / loop", 1: "A1 bodies + barrier", 2: "P1+P2 dist, rank, half-planes", 12: "LP2 groups + barrier",
-         3: "LP3 pass", 15: "A2c: float pos delta", 13: "A2c: atan2", 14: "A2c: wrap", 4: "A2c: rest of policy post",
+SLOTS = {0: "step entry / loop", 1: "A1 bodies + barrier", 2: "P2 rank, half-planes (+ pref on wave 0)", 12: "P2b 1-D programmes of all lines + barrier",
+         3: "LP3 pass", 15: "LP2 scan (wave 0) + queue + barrier", 13: "A2c: atan2", 14: "A2c: wrap", 4: "A2c: rest of policy post",
          5: "A2c: move (sincos) + bookkeeping", 6: "publish + ego frame + barrier", 7: "P3 pair dist / keys + barrier",
-         8: "A3 reward", 9: "P4 rank + emit + barrier", 10: "A4 done / reset + barrier(or)", 11: "reset-obs copy / copy-out / end sync"}
-ORDER = [0, 1, 2, 12, 3, 15, 13, 14, 4, 5, 6, 7, 8, 9, 10, 11]
+         8: "P4 round 1 + A3 reward (wave 0)", 9: "wait for P4 round 2 + barrier", 10: "A4 done / reset + barrier(or)", 11: "reset-obs copy / copy-out / end sync"}
+ORDER = [0, 1, 2, 12, 15, 3, 13, 14, 4, 5, 6, 7, 8, 9, 10, 11]
 
 E = int(os.environ.get("E", "4096"))
 steps = int(os.environ.get("STEPS", "200"))
@@ -56,6 +56,6 @@ n = min(wgs, 1024)
 t = a[:n].sum(axis=1)
 print("per-workgroup total (last launch): mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (
     t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max()))
-for sl in (12, 3, 2, 7, 9):
+for sl in (2, 12, 15, 3, 7, 8):
     c = a[:n, sl]
     print("  %-40s mean %.0f p90 %.0f max %.0f" % (SLOTS[sl], c.mean(), np.percentile(c, 90), c.max()))
