@@ -39,10 +39,15 @@ _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radi
 class CollisionAvoidanceEnv(Env):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
 
-    def __init__(self, num_envs=1, device="cuda:0"):
+    def __init__(self, num_envs=1, device="cuda:0", zero_copy=False):
+        """zero_copy (batched mode only): False -- step() / rollout() / reset() return FRESH tensors, like the
+        reference's DummyVecEnv returns fresh arrays every step (vec_env.py:120-135): safe to append to a rollout
+        buffer or to keep as prev_obs.  True -- they return the simulator's persistent device buffers, which the NEXT
+        launch overwrites in place (no copy; for consumers that read the outputs before stepping again)."""
         self.id = 0
         self.num_envs = int(num_envs)
         self.device = device
+        self.zero_copy = bool(zero_copy)
         self._initialize_rewards()
         self.num_agents = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
         self.dt_nominal = Config.DT
@@ -161,9 +166,10 @@ class CollisionAvoidanceEnv(Env):
             self._record_history()
         if self.num_envs > 1:
             # batched: 'laserscan' (if enabled) is the device tensor env.laserscan [E, N, 3, 512]
+            # (.bool() copies; obs / rewards are cloned unless zero_copy: the next launch rewrites the buffers in place)
             info = {"which_agents_done": sim.done.bool(),
                     "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
-            return sim.obs, sim.rewards, sim.game_over.bool(), False, info
+            return self._out(sim.obs), self._out(sim.rewards), sim.game_over.bool(), False, info
         rewards = sim.rewards[0].double().cpu().numpy()
         done = sim.done[0].cpu().numpy().astype(bool)
         game_over = bool(sim.game_over[0].item())
@@ -360,6 +366,10 @@ class CollisionAvoidanceEnv(Env):
             self._sim.state[name][e, a] = float(v)
         self._snap = None
 
+    def _out(self, t):
+        """a device output as handed to the caller: the persistent buffer itself (zero_copy) or a fresh copy"""
+        return t if self.zero_copy else t.clone()
+
     def _zero_obs(self):
         return {s: np.zeros(Config.STATE_INFO_DICT[s]["size"], dtype=Config.STATE_INFO_DICT[s]["dtype"])
                 for s in Config.STATES_IN_OBS}
@@ -368,7 +378,7 @@ class CollisionAvoidanceEnv(Env):
         """Batched: the device tensor [E, N, 6+7K].  Single env: the reference's nested dict
         {agent index: {state: array}} (:555-575); slots beyond the agents in the scene keep their zeros."""
         if self.num_envs > 1:
-            return self._sim.obs
+            return self._out(self._sim.obs)
         row = self._obs_host()[0]
         K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
         cols = {"is_learning": 0, "num_other_agents": 1, "dist_to_goal": 2, "heading_ego_frame": 3, "pref_speed": 4,
@@ -446,7 +456,7 @@ class CollisionAvoidanceEnv(Env):
                 {a.id: bool(d) for a, d in zip(self.agents, sim.done[0].cpu().numpy())},
                 "which_agents_learning": {a.id: a.policy.is_still_learning for a in self.agents}}
         if self.num_envs > 1:
-            return sim.obs, sim.rewards, sim.game_over.bool(), False, info
+            return self._out(sim.obs), self._out(sim.rewards), sim.game_over.bool(), False, info
         return self._get_obs(), sim.rewards[0].double().cpu().numpy(), bool(sim.game_over[0].item()), False, info
 
     def episode_stats(self):

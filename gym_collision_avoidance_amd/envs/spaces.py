@@ -1,6 +1,7 @@
 """Minimal gym-style containers (the `gym` package is not a dependency of the simulator): an Env base class and
 shape/dtype spaces with the attribute names RL code reads (low, high, shape, dtype, spaces).  If a real `gym` /
-`gymnasium` is installed, `register_with_gym()` in the package root exposes the env under the reference's id."""
+`gymnasium` is installed, `gym_collision_avoidance_amd.register_with_gym()` (called on import of the package root)
+exposes the env under the reference's id `CollisionAvoidance-v0`."""
 import numpy as np
 
 

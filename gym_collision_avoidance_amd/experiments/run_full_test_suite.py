@@ -41,15 +41,25 @@ def run_suite(policy="RVO", num_agents=4, test_cases=None, device="cuda:0", max_
     env.set_agents(per_env if len(cases) > 1 else per_env[0])
     env.reset()
     sim = env._sim
+    # run_episode stops an episode at game_over (env_utils.py:45-52); the batch keeps stepping until its slowest env is
+    # over, and the kernel keeps paying step rewards to the agents of finished envs (e.g. a timed-out agent standing
+    # within GETTING_CLOSE_RANGE of another one), so every per-episode quantity is LATCHED at the step its env finishes.
+    latched = ("t", "slt", "ep_reward", "flags")
     finish = torch.full((len(cases),), -1, dtype=torch.int32, device=sim.device)
+    keep = {k: sim.state[k].clone() for k in latched}
     for t in range(1, max_steps + 1):
         sim.step()
         over = sim.game_over.bool()
-        finish = torch.where((finish < 0) & over, torch.full_like(finish, t), finish)
-        if t % 64 == 0 and bool(over.all()):
+        newly = (finish < 0) & over
+        finish = torch.where(newly, torch.full_like(finish, t), finish)
+        for k in latched:
+            keep[k] = torch.where(newly[:, None], sim.state[k], keep[k])
+        if t % 64 == 0 and bool((finish >= 0).all()):
             break
+    for k in latched:   # envs that never finished within max_steps report their last state
+        keep[k] = torch.where((finish < 0)[:, None], sim.state[k], keep[k])
     finish = torch.where(finish < 0, torch.full_like(finish, t), finish).cpu().numpy()
-    st = {k: sim.state[k].cpu().numpy() for k in ("t", "slt", "ep_reward", "flags")}
+    st = {k: keep[k].cpu().numpy() for k in latched}
     fl = st["flags"].astype(np.uint32)
     coll, goal = (fl & nat.IN_COLLISION) != 0, (fl & nat.AT_GOAL) != 0
     rows = []
