@@ -32,7 +32,11 @@ def build(force=False, verbose=False, variant=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = OUT if variant is None else os.path.join(HERE, "libcagpu_%s.so" % variant)
     # "ablate_fast" / "knobs_fast": the same with only the N = 10 unstaged instantiations compiled (quick iterations)
-    extra = [] if variant is None else ["-DCAGPU_%s" % v.upper() for v in variant.split("_")]
+    # "exp<mask>_fast": compile-time experiment switches, -DCAGPU_EXP=<mask> (see EXP() in cagpu.hip)
+    # and "dKEY=VAL" -> -DCAGPU_KEY=VAL
+    extra = [] if variant is None else [("-DCAGPU_EXP=%s" % v[3:]) if v.startswith("exp") else
+                                        ("-DCAGPU_%s" % v[1:]) if (v.startswith("d") and "=" in v) else
+                                        "-DCAGPU_%s" % v.upper() for v in variant.split("_")]
     cmd = [hipcc] + FLAGS + extra + [SRC, "-o", out]
     if variant is not None:
         if verbose:

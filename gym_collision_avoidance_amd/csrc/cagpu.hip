@@ -368,7 +368,7 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 // walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
 constexpr int ROW = 64;
 constexpr int KEY_NONE = 2147483647;  // sort key of a pair that is not sensed (self, beyond the sensing horizon)
-#ifdef CAGPU_ABLATE
+#ifdef CAGPU_ABLATE  // experiment build (scratch/): run-time switches in k.ablate + in-kernel phase timers
 #define AB(bit) (k.ablate & (bit))
 #define DUP(bit) for (int rep_ = 0; rep_ < ((k.ablate & (bit)) ? 2 : 1); ++rep_)  // run an idempotent phase twice: its cost in situ
 __device__ unsigned long long g_prof[16];
@@ -379,6 +379,29 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 #define DUP(bit)
 #define TICK(slot) do {} while (0)
 #endif
+// Compile-time experiment switches (scratch/ builds: -DCAGPU_EXP=<bit mask>, libcagpu_exp<mask>_fast.so); 0 in the product
+#ifndef CAGPU_EXP
+#define CAGPU_EXP 0
+#endif
+#define EXP(bit) (((CAGPU_EXP) & (bit)) != 0)
+#define LP1_UNROLL _Pragma("unroll")
+// Workgroup barrier between phases that exchange data through LDS only: waits for this wave's LDS traffic, not for its
+// outstanding global stores (__syncthreads() = workgroup fence + barrier also drains vmcnt, i.e. every observation
+// store has to be acknowledged by the L2 before the phase after it may start).
+#if (CAGPU_EXP & 2)
+#define WG_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define WG_SYNC() __syncthreads()
+#endif
+// Wave priorities per phase (s_setprio 0..3).  Four workgroups share a CU, so every SIMD holds one wave of each of them,
+// usually in different phases.  The agent wave's serial chains (one lane per agent: they are what the workgroup's other
+// three waves are waiting for) and the linearProgram3 stragglers issue first, then pair phases in the order of the
+// step (a workgroup that is behind overtakes one that is ahead): 21.6 -> 20.3 us per step, rollout 14.1 -> 12.6
+// (profiles/r02_kernel_geometry.md; schemes 1-4 are the alternatives measured there, 0 = hardware default).
+#ifndef CAGPU_PRIO
+#define CAGPU_PRIO 5
+#endif
+#define PRIO(a, b, c, d, e) do { constexpr int pr_[6] = {0, a, b, c, d, e}; if (CAGPU_PRIO) __builtin_amdgcn_s_setprio(pr_[CAGPU_PRIO]); } while (0)
 // Pair items w = 0 .. n_items-1 are dealt to the NT threads in rounds; odd rounds run BACKWARDS over the threads, so the
 // last, partial round lands on the highest waves and wave 0 -- the agent wave -- is free for its one-lane-per-agent work
 // while the other waves finish the pair phase (400 items on 256 threads: wave 0 has one round, waves 2 and 3 two).
@@ -392,9 +415,10 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 #include "cagpu_ga3c.inc"
 
 // fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays) + the
-// linearProgram3 queue (length + up to ROW entries) + the exchange area of lp3_wave8 (8 float4 per wave)
+// linearProgram3 queue (length + up to ROW entries, then the number of ORCA queries) + the exchange area of lp3_wave8
+// (8 float4 per wave)
 __host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) {
-  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 1) * 4) + 8 * 8 * 16;
+  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 3) * 4) + 8 * 8 * 16;
 }
 // union, ORCA view: half-planes [N-1][CS] float4, the solution of every line's 1-D programme [N-1][CS] float2 + its
 // feasibility byte; the projected lines of linearProgram3 live in the registers of the solving group
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   float* sh_fprx = sh_vry + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
   int* sh_q3 = reinterpret_cast<int*>(sh_fpry + ROW);  // linearProgram3 queue: [0] = length, [1 ..] = entries
-  float4* sh_x3 = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sh_q3) + align16(static_cast<size_t>(ROW + 1) * 4));
+  float4* sh_x3 = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sh_q3) + align16(static_cast<size_t>(ROW + 3) * 4));
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
   // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
@@ -567,6 +591,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       const uint32_t pol = (r.flags >> CA_POLICY_SHIFT) & 0xF;
       const bool query = active && !(r.flags & CA_DONE);  // env.py:311
       const bool rvo = query && pol == CA_POL_RVO;
+      if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(2, 0, 3, 1, 2);
       if (wave0) {
         ep_step += 1;  // env.py:183
         sh_fpx[lane] = static_cast<float>(r.px);
@@ -583,11 +608,12 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           sh_q3[ROW + 1] = __popcll(qm);
         }
       }
-      __syncthreads();
+      WG_SYNC();
       TICK(1);
       F2 v_orca = f2(0.f, 0.f);  // this lane's ORCA velocity (agent wave)
+      PRIO(2, 0, 3, 1, 2);
       if (!AB(1)) {
-        // ================= P2: every (agent, other) pair: neighbour rank (ascending distSq, ties by index:
+        // ================= P2: every (querying agent, other) pair: neighbour rank (ascending distSq, ties by index:
         // Agent::insertAgentNeighbor) + ORCA half-plane
         const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
         const bool unlimited = !(range_sq < INFINITY);
@@ -595,48 +621,45 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
         const float collab = static_cast<float>(p.rvo_collab_coeff);
         const int n_live = sh_q3[ROW + 1];
-        const int n_orca = n_live * N;  // (querying agent, other) items
-        DUP(256)
+        // A wave holds WHOLE agents (floor(64 / N) of them, lane = (agent, other)), so a lane gets the other distances
+        // of its agent from its neighbour lanes (ds_bpermute: no recomputation, no LDS round trip) and counts its rank.
+        constexpr int NW = NT / 64;
+        const int wv = tid >> 6, wl = tid & 63;
+        const int apw = NC ? 64 / (NC ? NC : 1) : 64 / N;  // agents per wave
+        const int apr = NW * apw;                          // agents per round of the workgroup
+        const int g = static_cast<int>((static_cast<float>(wl) + 0.5f) * inv_n), j = wl - g * N;
+        const int gbase = (wl - j) << 2;  // ds_bpermute byte address of the first lane of my agent's group
 #pragma unroll
-        for (int base_ = 0, odd_ = 0; base_ < (NC ? n_items : n_orca); base_ += NT, odd_ ^= 1) {
-          const int w = base_ + (odd_ ? (NT - 1 - tid) : tid);
-          if (w >= n_orca) continue;
-          const int cag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-          const int j = w - cag * N;
-          const int ag = sh_q[cag];
+        for (int c0 = 0; c0 < (NC ? tile_n : n_live); c0 += apr) {
+          if (c0 >= n_live) continue;  // workgroup-uniform
+          const int c = c0 + wv * apw + g;
+          const bool valid = (g < apw) && (c < n_live);
+          const int ag = sh_q[valid ? c : 0];
           const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
           const F2 mpos = f2(sh_fpx[ag], sh_fpy[ag]);
           float dj = INFINITY;
-          if (j != aa) {
+          if (valid && j != aa) {
             const F2 d = mpos - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
             dj = dotf(d, d);
             if (!unlimited && !(dj < range_sq)) dj = INFINITY;
           }
-          int rank = 0, cnt = N - 1;
-          if (unlimited) {  // neighborDist = inf (Config.SENSING_HORIZON, RVOPolicy.py:27): every other agent is a neighbour
-            for (int q = 0; q < N; ++q) {
-              const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
-              float dq = dotf(d, d);
-              dq = (q != aa) ? dq : INFINITY;
-              rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
-            }
-          } else {
-            cnt = 0;
-            for (int q = 0; q < N; ++q) {
-              const F2 d = mpos - f2(sh_fpx[eb + q], sh_fpy[eb + q]);
-              float dq = dotf(d, d);
-              dq = (q != aa && dq < range_sq) ? dq : INFINITY;
-              rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));
-              cnt += static_cast<int>(dq < INFINITY);
-            }
+          int rank = 0, cnt = 0;
+#pragma unroll
+          for (int q = 0; q < N; ++q) {
+            const float dq = __int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj)));
+            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
+            cnt += static_cast<int>(dq < INFINITY);
           }
+          // (neighborDist = inf -- Config.SENSING_HORIZON, RVOPolicy.py:27 -- makes every other agent a neighbour)
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
-          if (j == aa) {
-            sh_nb[ag] = n;
-          } else if (dj < INFINITY && rank < n) {
-            Lmat[rank * CS + ag] = half_plane(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
-                                               f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
-                                               sh_frad[eb + j], collab, inv_h, ts);
+          if (valid) {
+            if (j == aa) {
+              sh_nb[ag] = n;
+            } else if (dj < INFINITY && rank < n) {
+              Lmat[rank * CS + ag] = half_plane(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
+                                                 f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
+                                                 sh_frad[eb + j], collab, inv_h, ts);
+            }
           }
         }
         if (wave0 && rvo) {  // the preferred velocity (float64 sqrt + divide), while the other waves finish the pairs
@@ -646,7 +669,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           sh_fpry[lane] = static_cast<float>(sc * vy);
           sh_fms[lane] = static_cast<float>(r.ps);
         }
-        __syncthreads();
+        WG_SYNC();
         TICK(2);
         // ================= P2b: linearProgram1 of EVERY line i against the lines before it, one thread per (agent, i).
         // The 1-D optimum on line i depends on the lines [0, i), the speed disc and the preferred velocity only -- not
@@ -657,8 +680,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         // loop over the lines m < i runs to a wave-uniform bound instead of N - 2 for everybody.
         const int n_lp1 = n_live * (N - 1);
         const float inv_live = 1.0f / static_cast<float>(n_live > 0 ? n_live : 1);
-        DUP(512)
-        for (int base_ = 0; base_ < n_lp1; base_ += NT) {
+                for (int base_ = 0; base_ < n_lp1; base_ += NT) {
           const int w = base_ + tid;
           const int w_hi = (base_ + (tid | 63) < n_lp1) ? base_ + (tid | 63) : n_lp1 - 1;  // the wave's last item
           const int i_hi = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(w_hi) + 0.5f) * inv_live));
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           float t_lo = -dp - sd;
           float t_hi = -dp + sd;
           if (base_ + (tid & ~63) < n_lp1) {  // wave-uniform: this wave has items in this round
-#pragma unroll 4
+LP1_UNROLL
             for (int m = 0; m < i_hi; ++m) {
               const bool use = m < i;
               const float4 lm = Lmat[(use ? m : 0) * CS + ag];
@@ -702,11 +724,12 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             okmat[i * CS + ag] = ok ? 1 : 0;
           }
         }
-        __syncthreads();
+        WG_SYNC();
         TICK(12);
         // ================= linearProgram2 = a scan over the lines, one lane per agent (agent wave); infeasible
         // programmes (4.6 % of the queries at N = 10) are queued for the cooperative linearProgram3 pass
         int failf = NOFAIL;
+        if (wave0) PRIO(3, 0, 3, 3, 3);
         if (wave0 && rvo) {
           const int n = sh_nb[lane];
           const float radius = sh_fms[lane];
@@ -735,13 +758,14 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = lane | (failf << 8);
           }
         }
-        __syncthreads();
+        WG_SYNC();
         TICK(15);
         // ================= linearProgram3 for the queued agents.  N <= 10 (at most 9 lines): one WAVE per agent, all pair
         // intersections of the embedded linearProgram2 in one step (lp3_wave8); otherwise one 16-lane group per agent
         // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
         const int n3 = sh_q3[0];
         if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+          PRIO(3, 3, 3, 2, 3);
           auto solve3 = [&](auto gs_tag) {
             constexpr int GS = decltype(gs_tag)::value;
             constexpr int GROUPS = NT / GS;
@@ -770,8 +794,9 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           } else {
             solve3(std::integral_constant<int, 64>{});
           }
-          __syncthreads();
+          WG_SYNC();
           if (failf != NOFAIL) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
+          if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(1, 0, 2, 0, 0);
         }
       }
       TICK(3);
@@ -882,11 +907,12 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         sh_sense[lane] = do_sense ? 1 : 0;
         if (RO) sh_q[lane] = 0;  // reused below: case index + 1 of an env that auto-resets in this step
       }
-      __syncthreads();
+      WG_SYNC();
       TICK(6);
 
       // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
       //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
+      PRIO(1, 0, 2, 1, 1);
       if (NC != 0 && p.sort_mode != CA_SORT_TIME_TO_IMPACT) {
         // N compiled in: one item per UNORDERED pair {a, b} -- the float64 square root, the collision gap and the
         // horizon test are the same for both directions; only d - r_host - r_other (operand order) and p_orth (the
@@ -977,10 +1003,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         gmat[j * CS + ag] = gap;
       }
       }
-      __syncthreads();
+      WG_SYNC();
 
       TICK(7);
       // ---- P4: rank the candidates of every agent and emit its rows (OtherAgentsStatesSensor.py:20-55,109-143)
+      PRIO(1, 0, 1, 1, 0);
       DUP(4096)
 #pragma unroll
       FOR_PAIR_ITEMS(w) {
@@ -1058,7 +1085,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         o7[6] = d2mat[j * CS + ag];
       }
       if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
-        __syncthreads();
+        WG_SYNC();
         FOR_PAIR_ITEMS(w) {
           const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
           const int j = w - ag * N;
@@ -1093,6 +1120,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       }
       // ---- A3 (wave 0, while the other waves finish the pair items of P4): rewards + collision flag (env.py:394-456),
       // observation scalars
+      if (wave0) PRIO(3, 0, 3, 3, 3);
       if (wave0 && active) {
         if (k.mode == MODE_STEP && pass == 0) {
           double nearest = INFINITY;
@@ -1137,7 +1165,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       }
 
       TICK(8);
-      __syncthreads();
+      WG_SYNC();
 
       TICK(9);
       // ---- A4 (wave 0): done / game over (env.py:514-553), auto-reset (vec_env.py:120-128), episode statistics
@@ -1197,6 +1225,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       const int again = __syncthreads_or(need_second ? 1 : 0);
       TICK(10);
       if (RO && again) {
+        __syncthreads();  // (full fence: the copy below overwrites observation rows other threads stored in P4)
         // ---- RO: the observation of a freshly reset env is a pure function of its fixture case: it was computed once
         // (cagpu_reset on the whole table) and is copied here, instead of a second sensing pass for the tile
         for (int le2 = 0; le2 < tile_envs; ++le2) {  // workgroup-uniform: at most a few envs of a tile reset per step
@@ -1212,7 +1241,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             else k.o.obs[tile_base * W + base + q] = v;
           }
         }
-        __syncthreads();
+        WG_SYNC();
       }
       if (RO || !again) {
         // ---- the tile's observation block leaves LDS as one contiguous, coalesced copy
@@ -1241,7 +1270,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
     } else if (sense_pass(0)) {
       sense_pass(1);
     }
-    __syncthreads();  // the union is free again before the next step's ORCA view
+    WG_SYNC();  // the union is free again before the next step's ORCA view
     TICK(11);
   };
   if (MULTI) {

@@ -155,19 +155,69 @@ static inline bool lp1(const std::vector<HalfPlane>& L, size_t k, float radius, 
 }
 
 // 2-D program (linearProgram2): returns the index of the first line that made it infeasible, or L.size().
+#ifdef ORCA_REF_STATS  // scratch/lp_stats.cpp only: how often the incremental program needs which 1-D programme
+struct LpStats {
+  long queries, no_violation_at_start, lp1_calls, lp1_not_flagged_at_start, flagged_at_start, lines, infeasible;
+  long hist_calls[16];
+  long flagged_margin[8], surprise_margin[8], query_surprise_margin[8];  // the same with "nearly violated" lines flagged too
+};
+static const float kLpStatsMargins[8] = {0.0f, 0.02f, 0.05f, 0.1f, 0.2f, 0.3f, 0.5f, 1.0f};
+static LpStats g_lp_stats;
+static std::vector<int> g_lp_log;  // per query: number of lines linearProgram3 acted on (-1: linearProgram2 was feasible)
+#endif
 static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt, bool dir_opt, Vec& res) {
   if (dir_opt) res = scl(radius, opt);  // opt * radius (commutative per component)
   else if (dot(opt, opt) > sq(radius)) res = scl(radius, unit(opt));
   else res = opt;
+#ifdef ORCA_REF_STATS
+  unsigned v0 = 0;
+  long calls = 0;
+  unsigned vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!dir_opt) {
+    for (int k = 0; k < 8; ++k) {
+      for (size_t i = 0; i < L.size(); ++i)
+        if (cross(L[i].dir, sub(L[i].pt, res)) > -kLpStatsMargins[k]) vm[k] |= 1u << i;
+      g_lp_stats.flagged_margin[k] += __builtin_popcount(vm[k]);
+    }
+    for (size_t i = 0; i < L.size(); ++i)
+      if (cross(L[i].dir, sub(L[i].pt, res)) > 0.0f) v0 |= 1u << i;
+    g_lp_stats.queries += 1;
+    g_lp_stats.lines += static_cast<long>(L.size());
+    g_lp_stats.no_violation_at_start += (v0 == 0);
+    g_lp_stats.flagged_at_start += __builtin_popcount(v0);
+  }
+#endif
   for (size_t i = 0; i < L.size(); ++i) {
     if (cross(L[i].dir, sub(L[i].pt, res)) > 0.0f) {
+#ifdef ORCA_REF_STATS
+      if (!dir_opt) {
+        ++calls;
+        g_lp_stats.lp1_calls += 1;
+        g_lp_stats.lp1_not_flagged_at_start += !((v0 >> i) & 1u);
+        for (int k = 0; k < 8; ++k)
+          if (!((vm[k] >> i) & 1u)) { g_lp_stats.surprise_margin[k] += 1; sm[k] = 1; }
+      }
+#endif
       const Vec keep = res;
       if (!lp1(L, i, radius, opt, dir_opt, res)) {
         res = keep;
+#ifdef ORCA_REF_STATS
+        if (!dir_opt) {
+          g_lp_stats.infeasible += 1;
+          g_lp_stats.hist_calls[calls < 15 ? calls : 15] += 1;
+          for (int k = 0; k < 8; ++k) g_lp_stats.query_surprise_margin[k] += sm[k];
+        }
+#endif
         return i;
       }
     }
   }
+#ifdef ORCA_REF_STATS
+  if (!dir_opt) {
+    g_lp_stats.hist_calls[calls < 15 ? calls : 15] += 1;
+    for (int k = 0; k < 8; ++k) g_lp_stats.query_surprise_margin[k] += sm[k];
+  }
+#endif
   return L.size();
 }
 
@@ -175,8 +225,14 @@ static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt,
 static inline void lp3(const std::vector<HalfPlane>& L, size_t begin, float radius, Vec& res) {
   float depth = 0.0f;
   std::vector<HalfPlane> P;
+#ifdef ORCA_REF_STATS
+  g_lp_log.push_back(0);
+#endif
   for (size_t i = begin; i < L.size(); ++i) {
     if (cross(L[i].dir, sub(L[i].pt, res)) > depth) {
+#ifdef ORCA_REF_STATS
+      g_lp_log.back() += 1;
+#endif
       P.clear();
       for (size_t j = 0; j < i; ++j) {
         HalfPlane h;
@@ -208,6 +264,9 @@ static inline Vec new_velocity(const Body* a, size_t n, size_t self, float neigh
   for (size_t i = 0; i < nb.size(); ++i) L.push_back(half_plane(a[self], a[nb[i].second], inv_h, time_step));
   Vec v;
   const size_t fail = lp2(L, a[self].max_speed, a[self].pref, false, v);
+#ifdef ORCA_REF_STATS
+  if (!(fail < L.size())) g_lp_log.push_back(-1);
+#endif
   if (fail < L.size()) lp3(L, fail, a[self].max_speed, v);
   return v;
 }
