@@ -252,6 +252,44 @@ __device__ __forceinline__ float4 half_plane(F2 mpos, F2 mvel, float mrad, F2 op
   return make_float4(pt.x, pt.y, dir.x, dir.y);
 }
 
+// The same half-plane without divergent branches (step kernel): the three cases of computeNewVelocity share ONE square
+// root and ONE reciprocal on selected inputs -- cut-off disc: sqrt(w.w), 1 / |w| (also the overlap case, which is the
+// cut-off disc of a one-step horizon); legs: sqrt(distSq - R^2), 1 / distSq -- so a wave whose lanes fall into different
+// cases runs the long dependent chain once instead of once per case.  Every selected expression is the one above:
+// bit-identical results (tests: the stand-alone cagpu_orca kernel keeps the branchy form, both match the oracle).
+__device__ __forceinline__ float4 half_plane_sel(F2 mpos, F2 mvel, float mrad, F2 opos, F2 ovel, float orad, float collab,
+                                                 float inv_h, float inv_dt) {
+  const F2 rp = opos - mpos;
+  const F2 rv = mvel - ovel;
+  const float d2 = dotf(rp, rp);
+  const float R = mrad + orad;
+  const float R2 = sqf(R);
+  const bool far = d2 > R2;
+  const float kk = far ? inv_h : inv_dt;
+  const F2 w = rv - kk * rp;
+  const float w2 = dotf(w, w);
+  const float dp1 = dotf(w, rp);
+  const bool disc = !far || (dp1 < 0.0f && sqf(dp1) > R2 * w2);
+  const float sq = sqrtf_rn(disc ? w2 : (d2 - R2));  // |w|  or  the leg length
+  const float inv = divf(1.0f, disc ? sq : d2);
+  // cut-off disc (and overlap)
+  const F2 uw = f2(w.x * inv, w.y * inv);
+  const F2 dir_a = f2(uw.y, -uw.x);
+  const F2 u_a = (R * kk - sq) * uw;
+  // legs
+  const bool left = detf(rp, w) > 0.0f;
+  const float bx = left ? (rp.x * sq - rp.y * R) : (rp.x * sq + rp.y * R);
+  const float by = left ? (rp.x * R + rp.y * sq) : (-rp.x * R + rp.y * sq);
+  const F2 t = f2(bx * inv, by * inv);
+  const F2 dir_b = left ? t : f2(-t.x, -t.y);
+  const float dp2 = dotf(rv, dir_b);
+  const F2 u_b = dp2 * dir_b - rv;
+  const F2 dir = disc ? dir_a : dir_b;
+  const F2 u = disc ? u_a : u_b;
+  const F2 pt = mvel + collab * u;
+  return make_float4(pt.x, pt.y, dir.x, dir.y);
+}
+
 // New ORCA velocity of the agent on this lane.  fpx/fpy/fvx/fvy/frad: the tile's float bodies in LDS,
 // `ebase` = LDS index of agent 0 of my env, `a` my agent index, N agents per env.  dcol: [N][STRIDE]
 // float scratch column, L / P: [N-1][STRIDE] float4 line columns (all already offset to my lane).
@@ -415,10 +453,9 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_
 #include "cagpu_ga3c.inc"
 
 // fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays) + the
-// linearProgram3 queue (length + up to ROW entries, then the number of ORCA queries) + the exchange area of lp3_wave8
-// (8 float4 per wave)
+// linearProgram3 queue (length + up to ROW entries, then the number of ORCA queries)
 __host__ __device__ inline size_t lds_fixed_bytes(int row = ROW) {
-  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 3) * 4) + 8 * 8 * 16;
+  return static_cast<size_t>(row) * (7 * 8 + 10 * 4 + 4 * 4) + align16(static_cast<size_t>(row + 3) * 4);
 }
 // union, ORCA view: half-planes [N-1][CS] float4, the solution of every line's 1-D programme [N-1][CS] float2 + its
 // feasibility byte; the projected lines of linearProgram3 live in the registers of the solving group
@@ -509,7 +546,6 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   float* sh_fprx = sh_vry + ROW;                      // its preferred velocity (float)
   float* sh_fpry = sh_fprx + ROW;
   int* sh_q3 = reinterpret_cast<int*>(sh_fpry + ROW);  // linearProgram3 queue: [0] = length, [1 ..] = entries
-  float4* sh_x3 = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sh_q3) + align16(static_cast<size_t>(ROW + 3) * 4));
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
   // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
@@ -618,7 +654,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         const float range_sq = sqf(static_cast<float>(p.sensing_horizon));
         const bool unlimited = !(range_sq < INFINITY);
         const float inv_h = divf(1.0f, static_cast<float>(p.rvo_time_horizon));
-        const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
+        const float inv_dt = divf(1.0f, static_cast<float>(p.rvo_dt));  // RVOPolicy.py:13,26
         const float collab = static_cast<float>(p.rvo_collab_coeff);
         const int n_live = sh_q3[ROW + 1];
         // A wave holds WHOLE agents (floor(64 / N) of them, lane = (agent, other)), so a lane gets the other distances
@@ -656,9 +692,9 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             if (j == aa) {
               sh_nb[ag] = n;
             } else if (dj < INFINITY && rank < n) {
-              Lmat[rank * CS + ag] = half_plane(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
-                                                 f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
-                                                 sh_frad[eb + j], collab, inv_h, ts);
+              Lmat[rank * CS + ag] = half_plane_sel(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
+                                                     f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
+                                                     sh_frad[eb + j], collab, inv_h, inv_dt);
             }
           }
         }
@@ -755,7 +791,7 @@ LP1_UNROLL
           if (failf != NOFAIL) {
             sh_vrx[lane] = res.x;
             sh_vry[lane] = res.y;
-            sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = lane | (failf << 8);
+            sh_q3[1 + atomicAdd(&sh_q3[0], 1)] = lane | (failf << 8) | (n << 16);
           }
         }
         WG_SYNC();
@@ -764,7 +800,7 @@ LP1_UNROLL
         // intersections of the embedded linearProgram2 in one step (lp3_wave8); otherwise one 16-lane group per agent
         // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
         const int n3 = sh_q3[0];
-        if (n3 > 0 && !AB(2)) {  // workgroup-uniform
+        if (n3 > 0 && !AB(2) && !EXP(8)) {  // workgroup-uniform (EXP(8): experiment, results invalid)
           PRIO(3, 3, 3, 2, 3);
           auto solve3 = [&](auto gs_tag) {
             constexpr int GS = decltype(gs_tag)::value;
@@ -773,7 +809,7 @@ LP1_UNROLL
             const int jl = tid & (GS - 1), g = tid / GS;
             constexpr int GPW = 64 / GS;  // groups per wave
             for (int q3 = (g % GPW) * (NT / 64) + (g / GPW); q3 < n3; q3 += GROUPS) {
-              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = ent >> 8;
+              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = (ent >> 8) & 0xFF;
               const int nf = sh_nb[agf];
               const float4 ln = Lmat[((jl < nf) ? jl : 0) * CS + agf];
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
@@ -784,9 +820,9 @@ LP1_UNROLL
           if (N <= 10) {
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
             for (int q3 = wv; q3 < n3; q3 += NT / 64) {
-              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = ent >> 8;
+              const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = (ent >> 8) & 0xFF;  // (bits 16 ..: the line count)
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
-              lp3_wave8(Lmat + agf, CS, sh_nb[agf], ff, sh_fms[agf], v, tid & 63, sh_x3 + 8 * wv);
+              lp3_wave8(Lmat + agf, CS, (ent >> 16) & 0xFF, ff, sh_fms[agf], v, tid & 63);
               if ((tid & 63) == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
             }
           } else if (N <= G16) {
