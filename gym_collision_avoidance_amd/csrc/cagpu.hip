@@ -417,6 +417,9 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 #define DUP(bit)
 #define TICK(slot) do {} while (0)
 #endif
+#ifdef CAGPU_WGTIME  // experiment build: per-workgroup wall-clock stamps of the LAST launch (100 MHz counter), no timers inside
+__device__ unsigned long long g_wgtime[4096 * 8];
+#endif
 // Compile-time experiment switches (scratch/ builds: -DCAGPU_EXP=<bit mask>, libcagpu_exp<mask>_fast.so); 0 in the product
 #ifndef CAGPU_EXP
 #define CAGPU_EXP 0
@@ -604,6 +607,10 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   __syncthreads();
   unsigned long long tprev_ = clock64();
 #endif
+#ifdef CAGPU_WGTIME
+  unsigned long long wg_t0 = 0, wg_info = 0;
+  if (tid == 0) wg_t0 = wall_clock64();
+#endif
   // The phases are straight-line code in the single-step kernel (lambdas inlined at their call sites): with the
   // n-step loop and the two-pass sensing loop around them the register allocator keeps ~100 more VGPRs alive around
   // the back edges (profiles/r01_kernel_geometry.md).  MULTI = true keeps the step loop for cagpu_rollout.
@@ -718,11 +725,22 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         const float inv_live = 1.0f / static_cast<float>(n_live > 0 ? n_live : 1);
                 for (int base_ = 0; base_ < n_lp1; base_ += NT) {
           const int w = base_ + tid;
-          const int w_hi = (base_ + (tid | 63) < n_lp1) ? base_ + (tid | 63) : n_lp1 - 1;  // the wave's last item
-          const int i_hi = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(w_hi) + 0.5f) * inv_live));
           const bool item = w < n_lp1;
-          const int i = item ? static_cast<int>((static_cast<float>(w) + 0.5f) * inv_live) : 0;
-          const int ag = sh_q[item ? w - i * n_live : 0];
+          int i_hi, i, ag;
+          if (!EXP(32)) {
+            // highest lines first: a second round (more than NT / (N - 1) queries in the tile) holds the lines with the
+            // FEWEST predecessors, i.e. the cheap ones
+            const int w_lo = base_ + (tid & ~63);  // the wave's first item holds its highest line
+            i_hi = __builtin_amdgcn_readfirstlane((N - 2) - static_cast<int>((static_cast<float>(w_lo) + 0.5f) * inv_live));
+            const int wq = item ? static_cast<int>((static_cast<float>(w) + 0.5f) * inv_live) : 0;
+            i = item ? (N - 2) - wq : 0;
+            ag = sh_q[item ? w - wq * n_live : 0];
+          } else {
+            const int w_hi = (base_ + (tid | 63) < n_lp1) ? base_ + (tid | 63) : n_lp1 - 1;  // the wave's last item
+            i_hi = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(w_hi) + 0.5f) * inv_live));
+            i = item ? static_cast<int>((static_cast<float>(w) + 0.5f) * inv_live) : 0;
+            ag = sh_q[item ? w - i * n_live : 0];
+          }
           const bool live = item && i < sh_nb[ag];
           const float4 li = Lmat[i * CS + ag];
           const F2 Pi = f2(li.x, li.y), Di = f2(li.z, li.w);
@@ -734,22 +752,25 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           const float sd = sqrtf_rn(ok ? disc : 0.0f);
           float t_lo = -dp - sd;
           float t_hi = -dp + sd;
+          auto against = [&](const int m) {  // intersect line i with line m (< i)
+            const bool use = m < i;
+            const float4 lm = Lmat[(use ? m : 0) * CS + ag];
+            const F2 Pm = f2(lm.x, lm.y), Dm = f2(lm.z, lm.w);
+            const float den = detf(Di, Dm);
+            const float num = detf(Dm, Pi - Pm);
+            const bool par = fabsf(den) <= kRvoEps;
+            ok = ok && !(use && par && num < 0.0f);
+            const float tt = divf(num, par ? 1.0f : den);
+            const float c_hi = (use && !par && den >= 0.0f) ? tt : INFINITY;
+            const float c_lo = (use && !par && den < 0.0f) ? tt : -INFINITY;
+            t_hi = (c_hi < t_hi) ? c_hi : t_hi;
+            t_lo = (t_lo < c_lo) ? c_lo : t_lo;
+          };
           if (base_ + (tid & ~63) < n_lp1) {  // wave-uniform: this wave has items in this round
+            // (run-time trip count on purpose: with all N - 2 iterations unrolled and every load hoisted the waves that
+            // hold low lines lose more than the others gain: 18.9 -> 19.3 us)
 LP1_UNROLL
-            for (int m = 0; m < i_hi; ++m) {
-              const bool use = m < i;
-              const float4 lm = Lmat[(use ? m : 0) * CS + ag];
-              const F2 Pm = f2(lm.x, lm.y), Dm = f2(lm.z, lm.w);
-              const float den = detf(Di, Dm);
-              const float num = detf(Dm, Pi - Pm);
-              const bool par = fabsf(den) <= kRvoEps;
-              ok = ok && !(use && par && num < 0.0f);
-              const float tt = divf(num, par ? 1.0f : den);
-              const float c_hi = (use && !par && den >= 0.0f) ? tt : INFINITY;
-              const float c_lo = (use && !par && den < 0.0f) ? tt : -INFINITY;
-              t_hi = (c_hi < t_hi) ? c_hi : t_hi;
-              t_lo = (t_lo < c_lo) ? c_lo : t_lo;
-            }
+            for (int m = 0; m < i_hi; ++m) against(m);
           }
           ok = ok && !(t_lo > t_hi);
           const float t = dotf(Di, opt - Pi);
@@ -800,6 +821,9 @@ LP1_UNROLL
         // intersections of the embedded linearProgram2 in one step (lp3_wave8); otherwise one 16-lane group per agent
         // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
         const int n3 = sh_q3[0];
+#ifdef CAGPU_WGTIME
+        if (tid == 0) wg_info = static_cast<unsigned long long>(n3) | (static_cast<unsigned long long>(sh_q3[ROW + 1]) << 8);
+#endif
         if (n3 > 0 && !AB(2) && !EXP(8)) {  // workgroup-uniform (EXP(8): experiment, results invalid)
           PRIO(3, 3, 3, 2, 3);
           auto solve3 = [&](auto gs_tag) {
@@ -1259,6 +1283,9 @@ LP1_UNROLL
         }
       }
       const int again = __syncthreads_or(need_second ? 1 : 0);
+#ifdef CAGPU_WGTIME
+      if (tid == 0 && again) wg_info |= 1ull << 16;
+#endif
       TICK(10);
       if (RO && again) {
         __syncthreads();  // (full fence: the copy below overwrites observation rows other threads stored in P4)
@@ -1321,6 +1348,10 @@ LP1_UNROLL
   if (tid < 16) atomicAdd(&g_prof[tid], sh_prof[tid]);
   if (tid < 16 && blockIdx.x < 1024) g_wgprof[blockIdx.x * 16 + tid] = sh_prof[tid];
 #endif
+#ifdef CAGPU_WGTIME
+  unsigned long long wg_t1 = 0;
+  if (tid == 0) wg_t1 = wall_clock64();
+#endif
   // ---- store my agent.  The pointers are re-read from the kernarg segment here (laundered so the compiler does
   // not keep 19 pointer pairs alive in SGPRs across the whole kernel).
   if (active && k.mode != MODE_OBSERVE && (k.mode == MODE_STEP || !k.reset_mask || k.reset_mask[e])) {
@@ -1343,6 +1374,15 @@ LP1_UNROLL
     ka->s.step_num[i] = r.step_num;
     if (a == 0) { ka->s.episode_step[e] = ep_step; ka->s.reset_count[e] = reset_cnt; }
   }
+#ifdef CAGPU_WGTIME
+  if (tid == 0 && blockIdx.x < 4096) {
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = g_wgtime + blockIdx.x * 8;
+    o[0] = wg_t0; o[1] = wg_t1; o[2] = wall_clock64(); o[3] = wg_info; o[4] = hw; o[5] = xcc;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- stand-alone ORCA (rvo2 doStep replacement)
@@ -1745,6 +1785,13 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
   return launch_any(k, stream);
 }
 
+#ifdef CAGPU_WGTIME
+int cagpu_debug_wgtime(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtime), sizeof(unsigned long long) * 4096 * 8);
+  return 0;
+}
+#endif
 #ifdef CAGPU_ABLATE
 int cagpu_debug_wgprof(unsigned long long* out) {
   hipDeviceSynchronize();

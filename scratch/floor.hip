@@ -25,6 +25,14 @@ __global__ __launch_bounds__(256) void k_ldst(Arr s, int spin) {
     if (spin > 0) {
 #pragma unroll 8
       for (int q = 0; q < spin; ++q) acc = __builtin_fma(acc, 1.0000001, v[1]);
+    } else if (spin < -100000) {  // four independent float chains, interleaved (does a wave issue them back to back?)
+      float f0 = (float)acc, f1 = f0 + 1.f, f2 = f0 + 2.f, f3 = f0 + 3.f, fb = (float)v[1];
+#pragma unroll 8
+      for (int q = 0; q < -spin - 100000; ++q) {
+        f0 = __builtin_fmaf(f0, 1.0000001f, fb); f1 = __builtin_fmaf(f1, 1.0000001f, fb);
+        f2 = __builtin_fmaf(f2, 1.0000001f, fb); f3 = __builtin_fmaf(f3, 1.0000001f, fb);
+      }
+      acc = (f0 + f1) + (f2 + f3);
     } else if (spin < 0) {  // float chain
       float fa = (float)acc, fb = (float)v[1];
 #pragma unroll 8
@@ -61,6 +69,6 @@ int main(int argc, char** argv) {
   printf("grid %d x 256 threads, %d B LDS\n", grid, lds);
   printf("empty kernel              %.2f us / launch\n", run(k_empty, s, 0, grid, lds, 2000));
   printf("load 16 + store 9 arrays  %.2f us / launch\n", run(k_ldst, s, 0, grid, lds, 2000));
-  for (int spin : {1000, 4000, -1000, -4000}) printf("  + %5d dependent FMAs (negative: f32) %.2f us / launch\n", spin, run(k_ldst, s, spin, grid, lds, 2000));
+  for (int spin : {1000, 4000, -1000, -4000, -101000, -104000}) printf("  + %5d dependent FMAs (negative: f32) %.2f us / launch\n", spin, run(k_ldst, s, spin, grid, lds, 2000));
   return 0;
 }

@@ -56,6 +56,11 @@ n = min(wgs, 1024)
 t = a[:n].sum(axis=1)
 print("per-workgroup total (last launch): mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (
     t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max()))
-for sl in (2, 12, 15, 3, 7, 8):
+for sl in ORDER:
     c = a[:n, sl]
-    print("  %-40s mean %.0f p90 %.0f max %.0f" % (SLOTS[sl], c.mean(), np.percentile(c, 90), c.max()))
+    print("  %-40s mean %5.0f p50 %5.0f p90 %5.0f p99 %5.0f max %5.0f" % (SLOTS[sl][:40], c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max()))
+# which phases make the slowest workgroups slow: mean of each phase over the slowest 1 % minus the overall mean
+slow = np.argsort(t)[-max(n // 100, 1):]
+print("slowest 1 %% of the workgroups (total %.0f vs mean %.0f): excess per phase" % (t[slow].mean(), t.mean()))
+for sl in ORDER:
+    print("  %-40s %+6.0f" % (SLOTS[sl][:40], a[slow, sl].mean() - a[:n, sl].mean()))
