@@ -664,14 +664,17 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         const float inv_dt = divf(1.0f, static_cast<float>(p.rvo_dt));  // RVOPolicy.py:13,26
         const float collab = static_cast<float>(p.rvo_collab_coeff);
         const int n_live = sh_q3[ROW + 1];
-        // A wave holds WHOLE agents (floor(64 / N) of them, lane = (agent, other)), so a lane gets the other distances
-        // of its agent from its neighbour lanes (ds_bpermute: no recomputation, no LDS round trip) and counts its rank.
+        // A wave holds WHOLE agents -- floor(64 / (N - 1)) of them, lane = (agent, one of its N - 1 others) -- so a lane
+        // gets the other distances of its agent from its neighbour lanes (ds_bpermute: no recomputation, no LDS round
+        // trip) and counts its rank.  At N = 10: 7 agents per wave, 28 per round of the workgroup.
         constexpr int NW = NT / 64;
         const int wv = tid >> 6, wl = tid & 63;
-        const int apw = NC ? 64 / (NC ? NC : 1) : 64 / N;  // agents per wave
-        const int apr = NW * apw;                          // agents per round of the workgroup
-        const int g = static_cast<int>((static_cast<float>(wl) + 0.5f) * inv_n), j = wl - g * N;
-        const int gbase = (wl - j) << 2;  // ds_bpermute byte address of the first lane of my agent's group
+        const int GN = NC ? (NC > 1 ? NC - 1 : 1) : (N > 1 ? N - 1 : 1);  // lanes per agent
+        const float inv_gn = 1.0f / static_cast<float>(GN);
+        const int apw = 64 / GN;     // agents per wave
+        const int apr = NW * apw;    // agents per round of the workgroup
+        const int g = static_cast<int>((static_cast<float>(wl) + 0.5f) * inv_gn), jo = wl - g * GN;
+        const int gbase = (wl - jo) << 2;  // ds_bpermute byte address of the first lane of my agent's group
 #pragma unroll
         for (int c0 = 0; c0 < (NC ? tile_n : n_live); c0 += apr) {
           if (c0 >= n_live) continue;  // workgroup-uniform
@@ -679,26 +682,26 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           const bool valid = (g < apw) && (c < n_live);
           const int ag = sh_q[valid ? c : 0];
           const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+          const int j = jo + ((jo >= aa) ? 1 : 0);  // my other agent (index order is kept: ties by index)
           const F2 mpos = f2(sh_fpx[ag], sh_fpy[ag]);
           float dj = INFINITY;
-          if (valid && j != aa) {
+          if (valid && j < N) {
             const F2 d = mpos - f2(sh_fpx[eb + j], sh_fpy[eb + j]);
             dj = dotf(d, d);
             if (!unlimited && !(dj < range_sq)) dj = INFINITY;
           }
           int rank = 0, cnt = 0;
 #pragma unroll
-          for (int q = 0; q < N; ++q) {
+          for (int q = 0; q < GN; ++q) {
             const float dq = __int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj)));
-            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < j));  // branch-free
+            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < jo));  // branch-free
             cnt += static_cast<int>(dq < INFINITY);
           }
           // (neighborDist = inf -- Config.SENSING_HORIZON, RVOPolicy.py:27 -- makes every other agent a neighbour)
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (valid) {
-            if (j == aa) {
-              sh_nb[ag] = n;
-            } else if (dj < INFINITY && rank < n) {
+            if (jo == 0) sh_nb[ag] = n;
+            if (dj < INFINITY && rank < n) {
               Lmat[rank * CS + ag] = half_plane_sel(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
                                                      f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
                                                      sh_frad[eb + j], collab, inv_h, inv_dt);
