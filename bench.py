@@ -115,7 +115,8 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
     n = max(20, min(a.steps, 200))
     if a.workload == "ga3c20":
         infer_s = _time_launches(lambda: sim.ga3c(), n, torch, dev)
-        flops = 2.0 * GA3C_MACS * E * N
+        rows = sim.ga3c_rows()   # agents evaluated by the timed launches (live GA3C-CADRL agents, packed by cagpu_ga3c)
+        flops = 2.0 * GA3C_MACS * rows
         out["metric"] = "agent-steps/sec at 4096 envs x 20 agents (GA3C-CADRL)"
         out["dtype"] = "f32 network (f32 MFMA), f64 simulator state"
         out["config"]["workload"] = ("configs[2]: %d envs/GPU x %d agents, GA3CCADRLPolicy (IROS18 checkpoint, LSTM-64 + "
@@ -126,9 +127,10 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
                            "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                            "kernel": "ga3c::ga3c_kernel", "avg_launch_us": infer_s * 1e6,
                            "algorithmic_flops_per_launch": flops, "macs_per_agent_query": GA3C_MACS,
-                           "note": "flops counted for 19 live LSTM steps per agent (every agent of a 20-agent env "
-                                   "observes 19 others); done agents are skipped by the reference but still cost a "
-                                   "tile row here"}
+                           "rows_evaluated": rows, "rows_total": E * N,
+                           "note": "flops counted for the %d agents that need an action (not done; the reference queries no "
+                                   "others), 19 live LSTM steps each (every agent of a 20-agent env observes 19 others); "
+                                   "cagpu_ga3c packs those rows first (CaNet.rows_scratch)" % rows}
     else:
         step_s = _time_launches(lambda: sim.step(), n, torch, dev)
         scan_s = _time_launches(lambda: sim.laserscan(), n, torch, dev)

@@ -66,7 +66,7 @@ NET_FIELDS = ("lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer
 
 
 class CaNet(C.Structure):
-    _fields_ = [(n, _P) for n in NET_FIELDS]
+    _fields_ = [(n, _P) for n in NET_FIELDS] + [("rows_scratch", _P)]
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",

@@ -120,6 +120,10 @@ class BatchedSim(object):
         cur.copy_((cur & 0x3F) | torch.as_tensor(bits.astype(np.int32), device=self.device))
         self._has_ga3c = bool((pol == nat.POL_GA3C_CADRL).any())
 
+    def ga3c_rows(self):
+        """number of agents the last ga3c() call evaluated (device -> host read: synchronises)"""
+        return int(self._net_tensors["rows_scratch"][-1].item())
+
     def load_ga3c(self, weights=None, keep_logits=False):
         """Upload the GA3C-CADRL network (GA3CCADRLPolicy.initialize_network, GA3CCADRLPolicy.py:23-47).  `weights`:
         an .npz written by oracle/extract_ga3c_weights.py (default: the shipped IROS18/network_01900000, the
@@ -139,8 +143,10 @@ class BatchedSim(object):
             if a.shape != shapes[f]:
                 raise ValueError("GA3C-CADRL weight %s has shape %s, expected %s" % (f, a.shape, shapes[f]))
             ts[f] = torch.from_numpy(a).to(self.device)
+        # scratch of cagpu_ga3c: the packed list of the agents that need an action this step (+ their count)
+        ts["rows_scratch"] = torch.zeros((self.E * self.N + 1,), dtype=torch.int32, device=self.device)
         self._net_tensors = ts
-        self._net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS})
+        self._net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch",)})
         self.ga3c_logits = torch.zeros((self.E, self.N, 11), dtype=torch.float32, device=self.device) \
             if keep_logits else None
 

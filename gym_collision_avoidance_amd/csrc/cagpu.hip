@@ -1755,6 +1755,12 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   k.B = static_cast<long>(p->num_envs) * p->num_agents;
   k.W = 6 + 7 * p->max_obs;
   k.net = *net; k.ext = ext_actions; k.logits = logits;
+  k.rows = net->rows_scratch;
+  if (k.rows) {
+    if (k.B >= (1L << 31)) return fail(CA_EUNSUPPORTED, "cagpu_ga3c: more than 2^31 agents with rows_scratch%s");
+    hipLaunchKernelGGL(ga3c::compact_kernel, dim3(1), dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B,
+                       net->rows_scratch);
+  }
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
   static thread_local bool lds_raised[16] = {false};
   int dev_id = 0;

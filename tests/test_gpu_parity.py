@@ -74,7 +74,7 @@ def _compare(o, g, tol=TOL, what=""):
 
 def test_library_loads_on_gpu():
     nat, core, orc = _mods()
-    assert nat.lib().cagpu_version() == 2
+    assert nat.lib().cagpu_version() == 3
     assert torch.cuda.is_available()
 
 
@@ -606,6 +606,14 @@ def test_ga3c_logits_and_actions_vs_numpy_network(E, N, K):
         assert np.array_equal(ex[live][clear, 0], np.argmax(want[live], axis=1)[clear])
         assert np.all(ex[live][:, 1] == 0.0) and np.all((ex[live][:, 0] >= 0) & (ex[live][:, 0] <= 10))
         assert np.array_equal(ex[live][:, 0], np.argmax(got[live], axis=1))      # first maximum, like np.argmax
+    # the packed list holds exactly the live rows; without it (CaNet.rows_scratch = NULL: whole tiles) the same bits
+    assert g.ga3c_rows() == int(live.sum())
+    g._net.rows_scratch = None
+    g.ga3c_logits.fill_(-777.0)
+    ext2 = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
+    g.ga3c(ext2)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.ga3c_logits.cpu().numpy(), got) and np.array_equal(ext2.cpu().numpy(), ex)
 
 
 def test_ga3c_needs_loaded_network():

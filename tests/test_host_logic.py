@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.cagpu_version.restype = ctypes.c_int
-    assert lib.cagpu_version() == 2   # host-only call, no GPU needed
+    assert lib.cagpu_version() == 3   # host-only call, no GPU needed
 
 
 def test_ctypes_structs_match_header_layout():
@@ -38,6 +38,7 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
     assert ctypes.sizeof(nat.CaAutoReset) == 40 and nat.CaAutoReset.reset_obs.offset == 32
     assert nat.CaParams.dt.offset == 32
+    assert ctypes.sizeof(nat.CaNet) == 13 * 8 and nat.CaNet.rows_scratch.offset == 12 * 8
     assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
     assert ctypes.sizeof(nat.CaScan) == 2 * 8 + 4 * 4 + 4 * 8 and nat.CaScan.min_angle.offset == 32
 
