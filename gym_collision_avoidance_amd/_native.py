@@ -70,7 +70,7 @@ class CaNet(C.Structure):
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases")
 
 _lib = None
 
@@ -100,6 +100,7 @@ def lib():
     L.cagpu_orca.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int32,
                              C.c_float, _P, _P]
     L.cagpu_ga3c.argtypes = [PP, PS, _P, C.POINTER(CaNet), _P, _P, _P]
+    L.cagpu_generate_cases.argtypes = [C.c_int64, C.c_int32] + [C.c_double] * 6 + [C.c_uint64, _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
         if n not in ("cagpu_last_error", "cagpu_last_kernel"):

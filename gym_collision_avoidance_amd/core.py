@@ -165,6 +165,21 @@ class BatchedSim(object):
                                       self._stream()))
         return ext
 
+    def generate_cases(self, num_cases, seed, side_length=4.0, speed_bnds=(0.5, 2.0), radius_bnds=(0.2, 0.8),
+                       return_status=False):
+        """`num_cases` random scenarios for this sim's agent count, drawn ON THE DEVICE by cagpu_generate_cases
+        (generate_rand_test_case_multi behind test_cases.get_testcase_random, test_cases.py:212-253): float64 device
+        tensor [num_cases, N, 6], ready for reset() / set_fixture_table().  `side_length`: a number, or (lo, hi) to draw
+        it per case like the reference's per-agent-count ranges.  Same (seed, case index) -> same scenario."""
+        lo, hi = (side_length, side_length) if np.isscalar(side_length) else side_length
+        out = torch.empty((int(num_cases), self.N, 6), dtype=torch.float64, device=self.device)
+        status = torch.zeros((int(num_cases),), dtype=torch.int32, device=self.device)
+        nat.check(self.lib.cagpu_generate_cases(int(num_cases), self.N, float(lo), float(hi), float(speed_bnds[0]),
+                                                float(speed_bnds[1]), float(radius_bnds[0]), float(radius_bnds[1]),
+                                                int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), status.data_ptr(),
+                                                self._stream()))
+        return (out, status) if return_status else out
+
     def set_fixture_table(self, table, env_id_offset=0, case_stride=None):
         """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,
         test_cases.py:593-624): env e's k-th reset loads case (env_id_offset + e + k*case_stride) % C."""

@@ -454,6 +454,7 @@ __device__ unsigned long long g_wgtime[4096 * 8];
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
 #include "cagpu_scan.inc"
 #include "cagpu_ga3c.inc"
+#include "cagpu_gen.inc"
 
 // fixed: 7 f64 + 10 f32 + 4 u32 per agent slot (the 3 f64 of the episode scratch alias six ORCA float arrays) + the
 // linearProgram3 queue (length + up to ROW entries, then the number of ORCA queries)
@@ -1775,6 +1776,26 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   const unsigned grid = static_cast<unsigned>((k.B + ga3c::TM - 1) / ga3c::TM);
   hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), ga3c::LDS_BYTES, static_cast<hipStream_t>(stream), k);
   e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
+}
+
+int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, double side_hi, double speed_lo,
+                         double speed_hi, double radius_lo, double radius_hi, uint64_t seed, double* cases, int32_t* status,
+                         void* stream) {
+  if (num_cases < 1 || num_agents < 1 || num_agents > 4096) return fail(CA_EINVAL, "cagpu_generate_cases: bad sizes%s");
+  if (!cases) return fail(CA_EINVAL, "cagpu_generate_cases: NULL cases%s");
+  if (!(side_lo > 0.0) || !(side_hi >= side_lo) || !(speed_lo > 0.0) || !(speed_hi >= speed_lo) || !(radius_lo > 0.0) ||
+      !(radius_hi >= radius_lo))
+    return fail(CA_EINVAL, "cagpu_generate_cases: bounds must be positive and ordered%s");
+  gen::Args a;
+  a.cases = cases; a.status = status; a.C = num_cases; a.N = num_agents;
+  a.side_lo = side_lo; a.side_hi = side_hi; a.speed_lo = speed_lo; a.speed_hi = speed_hi;
+  a.radius_lo = radius_lo; a.radius_hi = radius_hi; a.seed = seed;
+  a.max_attempts = 20000;  // the reference loops until a sample is accepted (its square / circle grows 1 % per retry)
+  hipLaunchKernelGGL(gen::generate_kernel, dim3(static_cast<unsigned>((num_cases + 63) / 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }

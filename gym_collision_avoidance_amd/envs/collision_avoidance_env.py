@@ -99,16 +99,27 @@ class CollisionAvoidanceEnv(Env):
         self._fixture = None
 
     def set_fixture_suite(self, num_agents, policies="RVO", agents_dynamics="unicycle", auto_reset=True,
-                          env_id_offset=0, case_stride=None, table=None):
+                          env_id_offset=0, case_stride=None, table=None, generate=None):
         """Batched evaluation on the reference's 500-case suite (run_full_test_suite.py:54-130): env e starts on case
         (env_id_offset + e) % 500 and, with auto_reset, its k-th episode loads case (env_id_offset + e + k*stride) % 500
-        on the device (DummyVecEnv semantics, vec_env.py:120-128)."""
-        # `table`: any float64 [C, num_agents, 6] case table instead of the reference's 500-case pickle, e.g. C scenarios
-        # drawn with envs/scenario_generator.py for on-device auto-reset during training
-        table = tc.fixture_table(num_agents) if table is None else np.ascontiguousarray(table, dtype=np.float64)
-        assert table.ndim == 3 and table.shape[1:] == (num_agents, 6), table.shape
+        on the device (DummyVecEnv semantics, vec_env.py:120-128).
+
+        `table`: any float64 [C, num_agents, 6] case table (numpy or device tensor) instead of the reference's pickle.
+        `generate`: dict(num_cases=..., seed=..., side_length=4.0 or (lo, hi), speed_bnds=(0.5, 2.0),
+        radius_bnds=(0.2, 0.8)) -- the table is drawn ON THE DEVICE by cagpu_generate_cases (the reference's
+        get_testcase_random, test_cases.py:212-253) when reset() builds the batch: training-mode resets then never touch
+        the host (initial headings point at the goal, as in EVALUATE_MODE)."""
+        if generate is not None:
+            assert table is None and int(generate["num_cases"]) >= 1 and "seed" in generate
+            table = None
+        elif table is None:
+            table = tc.fixture_table(num_agents)
+        elif not hasattr(table, "data_ptr"):
+            table = np.ascontiguousarray(table, dtype=np.float64)
+        if table is not None:
+            assert table.ndim == 3 and tuple(table.shape[1:]) == (num_agents, 6), table.shape
         self._fixture = dict(table=table, policies=policies, dynamics=agents_dynamics, auto_reset=auto_reset,
-                             env_id_offset=env_id_offset,
+                             env_id_offset=env_id_offset, num_agents=num_agents, generate=generate,
                              case_stride=self.num_envs if case_stride is None else case_stride)
         self.default_agents = None
 
@@ -186,9 +197,17 @@ class CollisionAvoidanceEnv(Env):
         if self._fixture is not None:
             f = self._fixture
             per_env = None  # built on the device from the table; only env 0 gets Agent views
+            if f["table"] is None:  # drawn on the device (cagpu_generate_cases); the sim only needs the agent count here
+                import torch
+                from gym_collision_avoidance_amd import core
+                gen = dict(f["generate"])
+                scratch = core.BatchedSim(core.make_params(1, f["num_agents"]), device=self.device)
+                f["table"] = scratch.generate_cases(gen.pop("num_cases"), gen.pop("seed"), **gen)
+                torch.cuda.synchronize()
             idx = (f["env_id_offset"] + 0) % len(f["table"])
-            self.agents = tc.cadrl_test_case_to_agents(f["table"][idx], policies=f["policies"],
-                                                       agents_dynamics=f["dynamics"])
+            row0 = f["table"][idx]
+            row0 = row0.cpu().numpy() if hasattr(row0, "cpu") else row0
+            self.agents = tc.cadrl_test_case_to_agents(row0, policies=f["policies"], agents_dynamics=f["dynamics"])
         else:
             if self.default_agents is None:
                 if E > 1 and self.test_case_args.get("num_agents") is not None:
@@ -277,6 +296,9 @@ class CollisionAvoidanceEnv(Env):
             sim.set_fixture_table(f["table"] if f["auto_reset"] else None, env_id_offset=f["env_id_offset"],
                                   case_stride=f["case_stride"])
             idx = (np.arange(E) + f["env_id_offset"]) % len(f["table"])
+            if hasattr(f["table"], "data_ptr"):
+                import torch
+                idx = torch.as_tensor(idx, device=f["table"].device)
             sim.reset(f["table"][idx])
             groups = [agents0]
         else:

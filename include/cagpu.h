@@ -220,6 +220,18 @@ int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const
 int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNet *net, double *ext_actions,
                float *logits, void *stream);
 
+/* Replaces: generate_rand_test_case_multi (envs/policies/CADRL/scripts/multi/gen_rand_testcases.py:111-444) behind
+ * test_cases.get_testcase_random (envs/test_cases.py:212-253), for num_cases scenarios at once: 15 % two-agent swap +
+ * circle, 15 % circle, 70 % rejection-sampled starts / goals in a square of half side `side` (drawn per case from
+ * [side_lo, side_hi] when side_hi > side_lo) that grows 1 % per attempt.  cases: device float64 [num_cases, num_agents, 6]
+ * = px, py, gx, gy, pref_speed, radius -- the layout cagpu_reset and CaAutoReset.table take.  Randomness is
+ * counter-based (Philox4x32-10 keyed by `seed`, counter = (draw, case index)): the same (seed, case index) gives the
+ * same scenario whatever num_cases is.  status: device int32 [num_cases] or NULL (0 = every agent was accepted by the
+ * reference's rules; 1 = an agent hit the attempt cap and was placed anyway). */
+int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, double side_hi, double speed_lo,
+                         double speed_hi, double radius_lo, double radius_hi, uint64_t seed, double *cases, int32_t *status,
+                         void *stream);
+
 /* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
  * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is
  * needed.  This is the batched form of env_utils.py:45-52 `while not terminated: env.step(None)`.

@@ -764,3 +764,61 @@ def test_auto_reset_without_precomputed_observations():
     for n in F64 + ("flags", "step_num", "episode_step", "reset_count", "env_stats"):
         assert torch.equal(sims[0].state[n], sims[1].state[n]), n
     assert torch.equal(sims[0].rewards, sims[1].rewards) and torch.equal(sims[0].done, sims[1].done)
+
+
+@pytest.mark.parametrize("N,side,seed", [(2, 4.0, 1), (4, 5.0, 2), (10, 4.0, 3), (10, (4.0, 8.0), 4), (20, 8.0, 5)])
+def test_device_scenarios_match_host_generator(N, side, seed):
+    """cagpu_generate_cases (section 8 f3: get_testcase_random on the device) against the host generator -- itself
+    bit-identical to the reference under np.random -- driven by the same Philox stream: the same draw order and the same
+    accept / reject decisions give the same scenarios (cos / sin of the circle families differ by an ulp between the
+    device's and the host's libm, hence 1e-9 and a little room for a borderline decision)"""
+    nat, core, orc = _mods()
+    from tests.test_host_logic import host_cases_from_philox
+    C_ = 96
+    g = core.BatchedSim(core.make_params(4, N))
+    got, status = g.generate_cases(C_, seed, side_length=side, return_status=True)
+    torch.cuda.synchronize()
+    got, status = got.cpu().numpy(), status.cpu().numpy()
+    want, kinds = host_cases_from_philox(seed, C_, N, side)
+    assert set(kinds) == {"swap", "circle", "rand"} and not status.any()
+    same = np.abs(got - want).reshape(C_, -1).max(axis=1) <= 1e-9
+    assert same.mean() >= 0.97, (same.mean(), [k for k, s_ in zip(kinds, same) if not s_])
+    # a case is a function of (seed, case index) alone
+    again = g.generate_cases(17, seed, side_length=side).cpu().numpy()
+    assert np.array_equal(again, got[:17])
+    other = g.generate_cases(17, seed + 1, side_length=side).cpu().numpy()
+    assert not np.array_equal(other, got[:17])
+
+
+def test_device_scenarios_statistics_and_training_reset():
+    """4096 generated 10-agent scenarios: family mix 15 / 15 / 70 %, the reference's clearance and trip-length rules,
+    speed = max of two uniforms, uniform radii; then used as the on-device auto-reset table of a stepping batch"""
+    nat, core, orc = _mods()
+    N, C_ = 10, 4096
+    g = core.BatchedSim(core.make_params(256, N))
+    cases, status = g.generate_cases(C_, 2024, side_length=(4.0, 6.0), return_status=True)
+    torch.cuda.synchronize()
+    cs, status = cases.cpu().numpy(), status.cpu().numpy()
+    assert not status.any() and np.isfinite(cs).all()
+    start, goal, speed, rad = cs[..., 0:2], cs[..., 2:4], cs[..., 4], cs[..., 5]
+    swap = (start[:, 0, 1] == 0.0) & (goal[:, 0, 1] == 0.0) & (start[:, 0, 0] == -start[:, 1, 0])
+    circle = ~swap & (np.abs(start + goal).reshape(C_, -1).max(axis=1) < 1e-9)   # antipodal around the origin
+    frac = np.array([swap.mean(), circle.mean(), (~swap & ~circle).mean()])
+    assert np.all(np.abs(frac - [0.15, 0.15, 0.70]) < 0.03), frac
+    d_start = np.linalg.norm(start[:, :, None] - start[:, None], axis=-1)
+    d_goal = np.linalg.norm(goal[:, :, None] - goal[:, None], axis=-1)
+    clr = rad[:, :, None] + rad[:, None] + 0.2
+    off = ~np.eye(N, dtype=bool)[None]
+    assert np.all((d_start >= clr) | ~off) and np.all((d_goal >= clr) | ~off)
+    trip = np.linalg.norm(start - goal, axis=-1)
+    assert np.all(trip[~swap & ~circle] > 0.5 * 4.0)      # > half of a side that only grows from its first value
+    assert np.all((speed >= 0.5) & (speed <= 2.0) & (rad >= 0.2) & (rad <= 0.8))
+    assert abs(speed.mean() - 1.5) < 0.01 and abs(rad.mean() - 0.5) < 0.01   # E max(U1, U2) = lo + 2/3 (hi - lo)
+    # training-mode resets straight from the generated table: nothing touches the host
+    g.set_plugins(nat.POL_RVO)
+    g.set_fixture_table(cases)
+    g.reset_from_table()
+    g.rollout(400)
+    torch.cuda.synchronize()
+    st = g.episode_stats().cpu().numpy()
+    assert st[0] > 100 and np.isfinite(g.obs.cpu().numpy()).all()
