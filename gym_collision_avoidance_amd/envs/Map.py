@@ -2,15 +2,35 @@
 
 The reference rebuilds `self.map` (static grid + every agent as a disc) on the host each step and hands it to the
 map-based sensors.  Here only the STATIC grid lives on the host; the per-step dynamic grid is assembled per env in
-LDS by the scan kernel (csrc/cagpu_scan.inc).  `map_filename` is not supported (the reference's loader needs
-imageio + scipy.misc.imresize); pass the grid as a bool array instead."""
+LDS by the scan kernel (csrc/cagpu_scan.inc).  `map_filename` is read like the reference does (Map.py:14-24: image ->
+nearest-neighbour resize to the grid -> np.invert -> bool, i.e. dark pixels are obstacles) with whichever of imageio /
+PIL is installed; `static_map` passes the grid directly as a bool array."""
 import numpy as np
+
+
+def load_map_image(map_filename, dims):
+    """Map.py:17-22 without scipy.misc.imresize (removed from SciPy): uint8 grey image, nearest resize, invert."""
+    try:
+        import imageio
+        img = np.asarray(imageio.imread(map_filename))
+    except ImportError:
+        from PIL import Image
+        img = np.asarray(Image.open(map_filename))
+    if img.ndim == 3:  # colour / alpha: the reference's maps are single-channel; take the first channel
+        img = img[..., 0]
+    if img.dtype == bool:
+        img = img.astype(np.uint8) * 255
+    img = img.astype(np.uint8)
+    if img.shape != tuple(dims):
+        from PIL import Image
+        img = np.asarray(Image.fromarray(img).resize((dims[1], dims[0]), Image.NEAREST))
+    return np.invert(img).astype(bool)
 
 
 class Map(object):
     def __init__(self, x_width, y_width, grid_cell_size, map_filename=None, static_map=None):
         if map_filename is not None:
-            raise NotImplementedError("loading map images is not supported: pass static_map=<bool array>")
+            static_map = load_map_image(map_filename, (int(x_width / grid_cell_size), int(y_width / grid_cell_size)))
         self.x_width, self.y_width, self.grid_cell_size = x_width, y_width, grid_cell_size
         dims = (int(self.x_width / self.grid_cell_size), int(self.y_width / self.grid_cell_size))
         if static_map is None:

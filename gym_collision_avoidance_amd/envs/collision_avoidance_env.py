@@ -124,11 +124,10 @@ class CollisionAvoidanceEnv(Env):
         self.default_agents = None
 
     def set_static_map(self, static_map):
-        """The static obstacles used when Config.USE_STATIC_MAP: a bool array [160, 160] (True = occupied; row =
-        floor(80 - y/0.1), col = floor(80 + x/0.1), Map.py:26-32) or None for an empty map.  (The reference takes an
-        image file name here, collision_avoidance_env.py:369-376; its loader needs imageio + scipy.misc.imresize.)"""
-        if isinstance(static_map, str):
-            raise NotImplementedError("pass the occupancy grid as a bool array, not an image file name")
+        """The static obstacles used when Config.USE_STATIC_MAP (collision_avoidance_env.py:369-392): the path of a
+        binary image file like the reference takes (or a list of paths, one drawn per episode), OR the occupancy grid
+        itself as a bool array [160, 160] (True = occupied; row = floor(80 - y/0.1), col = floor(80 + x/0.1),
+        Map.py:26-32), or None for an empty map."""
         self.static_map_filename = static_map
 
     def set_plot_save_dir(self, plot_save_dir):
@@ -331,7 +330,10 @@ class CollisionAvoidanceEnv(Env):
                     agent._bind(self, e, a_idx)
         self._snap, self._obs_np, self._scan_np = None, None, None
         if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
-            self.map = Map(16, 16, 0.1, static_map=self.static_map_filename)
+            sm = self.static_map_filename
+            if isinstance(sm, list) and sm and isinstance(sm[0], str):
+                sm = np.random.choice(sm)  # collision_avoidance_env.py:384-385
+            self.map = Map(16, 16, 0.1, map_filename=sm) if isinstance(sm, str) else Map(16, 16, 0.1, static_map=sm)
             sim.set_map(self.map.static_map if self.map.static_map.any() else None, num_beams=Config.LASERSCAN_LENGTH,
                         num_to_store=Config.LASERSCAN_NUM_PAST)
             sim.laserscan()

@@ -12,13 +12,17 @@ class RVOPolicy(InternalPolicy):
     entry point `cagpu_orca`).  Parameters follow RVOPolicy.py:13-28: timeStep = Config.DT, neighborDist =
     SENSING_HORIZON, maxNeighbors = MAX_NUM_AGENTS_IN_ENVIRONMENT, timeHorizon = RVO_TIME_HORIZON, per-agent
     radius * 1.05 and maxSpeed = pref_speed; the pi/6 turn clip of :109-111 is applied in the kernel.
-    Not supported (raise): has_fixed_speed / heading_noise / negative RVO_COLLAB_COEFF (np.random paths)."""
+    The reference's optional branches: `has_fixed_speed` reads `self.max_speed`, which RVOPolicy never defines
+    (RVOPolicy.py:114-115 raises AttributeError when switched on), so there is no behaviour to mirror; `heading_noise`
+    (np.random.normal per query, :118-119) and a negative RVO_COLLAB_COEFF (np.random.choice every RVO_ANTI_COLLAB_T
+    seconds, :77-88) draw from numpy's global stream per agent and per step: not reproducible on the device, they
+    raise here (both are off in every shipped config)."""
     kernel_id = nat.POL_RVO
 
     def __init__(self):
         InternalPolicy.__init__(self, str="RVO")
         self.dt = Config.DT
-        self.has_fixed_speed = False
+        self.has_fixed_speed = False   # (see the class docstring)
         self.heading_noise = False
         self.max_delta_heading = np.pi / 6
         if Config.RVO_COLLAB_COEFF < 0:

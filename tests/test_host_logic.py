@@ -301,3 +301,21 @@ def test_philox_stream_and_host_generator_under_it():
                 clr = cs[i, 5] + cs[j, 5] + 0.2
                 assert np.hypot(*(cs[i, 0:2] - cs[j, 0:2])) >= clr and np.hypot(*(cs[i, 2:4] - cs[j, 2:4])) >= clr
         assert np.all((cs[:, 4] >= 0.5) & (cs[:, 4] <= 2.0) & (cs[:, 5] >= 0.2) & (cs[:, 5] <= 0.8))
+
+
+def test_map_image_loading(tmp_path):
+    """Map(map_filename=...) like the reference's loader (Map.py:14-24): dark pixels are obstacles, images of another
+    size are resized to the grid with nearest-neighbour sampling"""
+    from PIL import Image
+    from gym_collision_avoidance_amd.envs.Map import Map
+    img = np.full((160, 160), 255, dtype=np.uint8)
+    img[40:44, 30:130] = 0
+    f = str(tmp_path / "world.png")
+    Image.fromarray(img).save(f)
+    m = Map(16, 16, 0.1, map_filename=f)
+    assert m.static_map.shape == (160, 160) and m.static_map.dtype == bool
+    assert m.static_map[40:44, 30:130].all() and m.static_map.sum() == 4 * 100
+    big = np.kron(img, np.ones((2, 2), dtype=np.uint8))  # 320 x 320
+    f2 = str(tmp_path / "world2.png")
+    Image.fromarray(big).save(f2)
+    assert np.array_equal(Map(16, 16, 0.1, map_filename=f2).static_map, m.static_map)
