@@ -60,8 +60,8 @@ def test_map_indices_and_laserscan_sensor_registration():
     assert Config.STATE_INFO_DICT["laserscan"]["size"] == (3, 512)
     env = Env()
     assert env.observation_space.spaces[0].spaces["laserscan"].shape == (3, 512)
-    with pytest.raises(NotImplementedError):
-        env.set_static_map("world_maps/002.png")
+    env.set_static_map("world_maps/002.png")   # a path like the reference takes (read when the episode starts)
+    assert env.static_map_filename == "world_maps/002.png"
     envtools.default()
 
 
