@@ -1722,11 +1722,14 @@ int cagpu_laserscan(const CaParams* p, const CaState* s, const CaMap* map, const
       scan->num_ranges > 255)
     return fail(CA_EINVAL, "cagpu_laserscan: bad CaScan%s");
   if (!s->pos_x || !s->pos_y || !s->heading || !s->radius || !s->step_num) return fail(CA_EINVAL, "cagpu_laserscan: NULL state pointer%s");
+  if (!(scan->range_res / map->cell + 0.2 < SCAN_PAD - 1))
+    return fail(CA_EUNSUPPORTED, "cagpu_laserscan: range_res above 6 cells is not supported (LDS bitmap border)%s");
   ScanArgs k;
   std::memset(&k, 0, sizeof(k));
   k.p = *p; k.s = *s; k.m = *map; k.sc = *scan;
-  const int N = p->num_agents, wpr = (map->cols + 31) >> 5;
-  const size_t total = align16(static_cast<size_t>(map->rows) * wpr * 4) + static_cast<size_t>(N) * (4 * 8 + 2 * 8 + 3 * 4) + 16;
+  const int N = p->num_agents;
+  const size_t total = align16(scan_grid_words(map->rows, map->cols) * 4) + static_cast<size_t>(N) * (4 * 8 + 2 * 8 + 3 * 4 + 2 * 8) +
+                       static_cast<size_t>(scan->num_beams) * 16 + 32;
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu_laserscan: map too large for the LDS bitmap%s");
   if (total > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel),
