@@ -23,3 +23,12 @@ timeout 600 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_
 find $O -name '*agent_info.csv' -delete
 ls -la $O
 du -sh $O
+# the "next"-row workloads (their own bench lines; profiles/r02_bench_*.json)
+cd $R
+timeout 600 python bench.py --workload ga3c20 --steps 100 --warmup 10 > $O/bench_ga3c20.json 2> $O/bench_ga3c20.err
+timeout 600 python bench.py --workload crowd50_laser --steps 50 --warmup 5 > $O/bench_crowd50.json 2> $O/bench_crowd50.err
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ga3c -- python $R/bench.py --workload ga3c20 --steps 100 --warmup 10 --no-cpu-baseline > $O/prof_ga3c.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_crowd -- python $R/bench.py --workload crowd50_laser --steps 50 --warmup 5 --no-cpu-baseline > $O/prof_crowd.log 2>&1
+find $O -name '*agent_info.csv' -delete
+du -sh $O
