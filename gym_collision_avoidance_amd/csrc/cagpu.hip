@@ -1229,7 +1229,9 @@ LP1_UNROLL
       }
 
       TICK(8);
-      WG_SYNC();
+      // No workgroup barrier here: A4 reads what A3 wrote (flags, episode scratch), and both run on the agent wave --
+      // a wave-level fence is enough, and A4 overlaps with the other waves' second round of P4 instead of following it.
+      if (wave0) wave_sync();
 
       TICK(9);
       // ---- A4 (wave 0): done / game over (env.py:514-553), auto-reset (vec_env.py:120-128), episode statistics
@@ -1337,7 +1339,7 @@ LP1_UNROLL
     } else if (sense_pass(0)) {
       sense_pass(1);
     }
-    WG_SYNC();  // the union is free again before the next step's ORCA view
+    if (MULTI || EXP(4)) WG_SYNC();  // the union is free again before the next step's ORCA view (n-step kernel only)
     TICK(11);
   };
   if (MULTI) {
