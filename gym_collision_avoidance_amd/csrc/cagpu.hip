@@ -1778,7 +1778,14 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
     lds_raised[dev_id & 15] = true;
   }
-  const unsigned grid = static_cast<unsigned>((k.B + ga3c::TM - 1) / ga3c::TM);
+  k.slots = 2 * device_cus();
+  k.force_tile = 0;
+#if defined(CAGPU_KNOBS)
+  if (const char* ft = std::getenv("CAGPU_GA3C_TILE")) k.force_tile = std::atoi(ft);
+#endif
+  // the tile height (64 / 48 / 32 rows) is chosen on the device from the number of live rows: the grid covers the worst
+  // case (32-row tiles); workgroups beyond the last tile leave at once
+  const unsigned grid = static_cast<unsigned>((k.B + 31) / 32);
   hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), ga3c::LDS_BYTES, static_cast<hipStream_t>(stream), k);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
