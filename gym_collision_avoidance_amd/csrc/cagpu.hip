@@ -396,6 +396,21 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 
 #include "cagpu_grouplp.inc"
 
+// for (q = 0; q < n; ++q) body(q) in blocks of BLK: with a run-time n (the generic kernel) the loads of a block are in
+// flight together instead of one LDS round trip per iteration (N = 50: the rank loop of the sensor took 57 k of the
+// step's 155 k cycles as a plain loop); with a compile-time n everything unrolls as before.
+template <int BLK, typename F>
+__device__ __forceinline__ void for_n(const int n, F&& body) {
+  int q = 0;
+  for (; q + BLK <= n; q += BLK) {
+#pragma unroll
+    for (int u = 0; u < BLK; ++u) body(q + u);
+  }
+#pragma unroll
+  for (int u = 0; u < BLK - 1; ++u)
+    if (q + u < n) body(q + u);
+}
+
 // ---------------------------------------------------------------- main kernel
 // Work decomposition of one tile (ROW = 64 agent slots = floor(64/N) whole envs) on a workgroup of NT threads:
 //   agent phases  (A*): one LANE per agent, on wave 0 only -- the serial per-agent chains (incremental LP,
@@ -692,12 +707,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             if (!unlimited && !(dj < range_sq)) dj = INFINITY;
           }
           int rank = 0, cnt = 0;
-#pragma unroll
-          for (int q = 0; q < GN; ++q) {
+          for_n<8>(GN, [&](const int q) {
             const float dq = __int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj)));
             rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < jo));  // branch-free
             cnt += static_cast<int>(dq < INFINITY);
-          }
+          });
           // (neighborDist = inf -- Config.SENSING_HORIZON, RVOPolicy.py:27 -- makes every other agent a neighbour)
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (valid) {
@@ -797,8 +811,7 @@ LP1_UNROLL
           const F2 opt = f2(sh_fprx[lane], sh_fpry[lane]);
           F2 res = opt;
           if (dotf(opt, opt) > sqf(radius)) res = radius * unitf(opt);
-#pragma unroll
-          for (int i = 0; i < (NC ? NC - 1 : n); ++i) {
+          for_n<8>(NC ? NC - 1 : n, [&](const int i) {
             // The loads do not depend on the running result, so all of them can be in flight before the select chain
             // starts -- provided the tests stay branch-free: the conditions are combined as integers (written with &&
             // the compiler guards every load with its own branch + wait, one LDS round trip per line).
@@ -811,7 +824,7 @@ LP1_UNROLL
             res.x = take ? ri.x : res.x;
             res.y = take ? ri.y : res.y;
             failf = (hit & (take ^ 1)) ? i : failf;
-          }
+          });
           v_orca = res;
           if (failf != NOFAIL) {
             sh_vrx[lane] = res.x;
@@ -1086,7 +1099,7 @@ LP1_UNROLL
         if (p.sort_mode == CA_SORT_TIME_TO_IMPACT) {  // key (-tti, -dist, p_orth), sensor :36-38
           const bool vj = kj != KEY_NONE;
           const double tj = vj ? tmat[j * CS + ag] : 0.0;
-          for (int q = 0; q < N; ++q) {
+          for_n<8>(N, [&](const int q) {
             const int kq = kmat[q * CS + ag];
             const double oq = omat[q * CS + ag];
             const bool vq = kq != KEY_NONE;
@@ -1096,27 +1109,27 @@ LP1_UNROLL
             const int before = static_cast<int>(tq > tj) | (static_cast<int>(tq == tj) & lk);
             rank += static_cast<int>(vq) & static_cast<int>(vj) & before;
             cnt += static_cast<int>(vq);
-          }
+          });
         } else {
           // Pass 1 ranks by the distance bucket alone (one 4-byte key per candidate, branch-free).  Two candidates of
           // an agent share a 1 cm bucket in a few per cent of the rows only: the (p_orth, index) tie-break -- an 8-byte
           // load and two float64 compares per candidate -- runs as a second pass in the waves that hold such a row.
           int same = 0;
-          for (int q = 0; q < N; ++q) {
+          for_n<8>(N, [&](const int q) {
             const int kq = kmat[q * CS + ag];
             rank += static_cast<int>(kq < kj);
             same += static_cast<int>(kq == kj);
-          }
+          });
           if (__any(same > 1)) {  // (a key always equals itself)
-            for (int q = 0; q < N; ++q) {
+            for_n<8>(N, [&](const int q) {
               const int kq = kmat[q * CS + ag];
               const double oq = omat[q * CS + ag];
               rank += static_cast<int>(kq == kj) &
                       (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j)));
-            }
+            });
           }
           if (p.sensing_horizon < INFINITY) {
-            for (int q = 0; q < N; ++q) cnt += static_cast<int>(kmat[q * CS + ag] != KEY_NONE);
+            for_n<8>(N, [&](const int q) { cnt += static_cast<int>(kmat[q * CS + ag] != KEY_NONE); });
           } else {
             cnt = N - 1;  // every other agent of the env is sensed
           }
@@ -1160,13 +1173,13 @@ LP1_UNROLL
           const int kj = kmat[j * CS + ag];
           const double oj = omat[j * CS + ag];
           int r2 = 0;
-          for (int q = 0; q < N; ++q) {
+          for_n<8>(N, [&](const int q) {
             const int rq = rmat[q * CS + ag];
             const int kq = kmat[q * CS + ag];
             const double oq = omat[q * CS + ag];
             const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(rq < rank));
             r2 += static_cast<int>(rq < N) & (static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo));
-          }
+          });
           float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
@@ -1188,10 +1201,10 @@ LP1_UNROLL
       if (wave0 && active) {
         if (k.mode == MODE_STEP && pass == 0) {
           double nearest = INFINITY;
-          for (int j = 0; j < N; ++j) {
+          for_n<8>(N, [&](const int j) {
             const double g = gmat[j * CS + lane];
             nearest = (g < nearest) ? g : nearest;
-          }
+          });
           const bool coll = nearest <= 0.0;  // some d <= r_i + r_j  <=>  min(d - (r_i + r_j)) <= 0
           double rw = p.reward_time_step;
           if (r.flags & CA_AT_GOAL) {
@@ -1242,12 +1255,12 @@ LP1_UNROLL
           // AND / OR of the env's flag words, then bit tests: no short-circuit chains (they compile to one dependent
           // LDS round trip + branch per agent)
           uint32_t f_and = ~0u, f_or = 0u, learn_and = ~0u;
-          for (int j = 0; j < N; ++j) {
+          for_n<8>(N, [&](const int j) {
             const uint32_t f = sh_flag[ebase + j];
             f_and &= f;
             f_or |= f;
             learn_and &= (f & CA_STILL_LEARNING) ? f : ~0u;  // learners only
-          }
+          });
           const bool all_done = (f_and & CA_DONE) != 0, all_learning_done = (learn_and & CA_DONE) != 0;
           const bool any_coll = (f_or & CA_IN_COLLISION) != 0, all_goal = (f_and & CA_AT_GOAL) != 0;
           bool over = all_done;
@@ -1259,11 +1272,11 @@ LP1_UNROLL
           if (over && k.table) {
             if (a == 0) {  // experiments/src/env_utils.py:56-87 reduced to counters, summed in agent order
               double tot_r = 0.0, ttg = 0.0, extra = 0.0;
-              for (int j = 0; j < N; ++j) {
+              for_n<8>(N, [&](const int j) {  // (summed in agent order)
                 tot_r += sh_r0[ebase + j];
                 ttg += sh_r1[ebase + j];
                 extra += sh_r2[ebase + j];
-              }
+              });
               double* st = k.s.env_stats + 8 * e;
               st[0] += 1.0;
               if (any_coll) st[1] += 1.0;

@@ -21,8 +21,9 @@ ORDER = [0, 1, 2, 12, 15, 3, 13, 14, 4, 5, 6, 7, 8, 9, 10, 11]
 E = int(os.environ.get("E", "4096"))
 steps = int(os.environ.get("STEPS", "200"))
 mode = os.environ.get("MODE", "step")
-table = np.load(os.path.join(os.path.dirname(nat.HERE), "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n10"]
-sim = core.BatchedSim(core.make_params(E, 10))
+NA = int(os.environ.get("N", "10"))
+table = np.load(os.path.join(os.path.dirname(nat.HERE), "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % NA]
+sim = core.BatchedSim(core.make_params(E, NA))
 sim.set_plugins(nat.POL_RVO)
 sim.set_fixture_table(table)
 sim.reset_from_table()
