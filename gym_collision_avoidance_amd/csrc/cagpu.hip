@@ -732,6 +732,29 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         }
         WG_SYNC();
         TICK(2);
+        if (NC == 0 && N > G16 && !EXP(32)) {
+          // ================= more than 16 agents per env: one WAVE per querying agent solves the whole programme
+          // cooperatively (lane j = line j): linearProgram2 as "first violated line" ballots with the 1-D programme of that
+          // line solved by the lanes holding the lines before it, then linearProgram3 if it ends infeasible
+          // (cagpu_grouplp.inc; bit-identical to the sequential algorithm).  Solving EVERY line's 1-D programme in advance,
+          // as below, is N^3 / 2 intersections per env -- at N = 50 that and its scan took 37 k of the step's 138 k cycles,
+          // for 1.3 .. 3 programmes a query really needs.
+          const int wq = tid >> 6, jl = tid & 63;
+          for (int c = wq; c < n_live; c += NT / 64) {  // wave-uniform
+            const int ag = sh_q[c];
+            const int nf = sh_nb[ag];
+            const float4 ln = Lmat[((jl < nf) ? jl : 0) * CS + ag];
+            F2 v;
+            const int f2_ = lp2_group<64>(jl < nf, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[ag], f2(sh_fprx[ag], sh_fpry[ag]), false,
+                                          v, jl, jl);
+            if (f2_ != NOFAIL) lp3_group<64>(nf, f2_, f2(ln.x, ln.y), f2(ln.z, ln.w), sh_fms[ag], v, jl, jl);
+            if (jl == 0) { sh_vrx[ag] = v.x; sh_vry[ag] = v.y; }
+          }
+          WG_SYNC();
+          TICK(12);
+          if (wave0 && rvo) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
+          if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(1, 0, 2, 0, 0);
+        } else {
         // ================= P2b: linearProgram1 of EVERY line i against the lines before it, one thread per (agent, i).
         // The 1-D optimum on line i depends on the lines [0, i), the speed disc and the preferred velocity only -- not
         // on the running result of linearProgram2 -- so all of them are computed side by side (min / max are exact and
@@ -874,6 +897,7 @@ LP1_UNROLL
           WG_SYNC();
           if (failf != NOFAIL) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
           if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(1, 0, 2, 0, 0);
+        }
         }
       }
       TICK(3);
