@@ -453,11 +453,14 @@ __device__ unsigned long long g_wgtime[4096 * 8];
 // usually in different phases.  The agent wave's serial chains (one lane per agent: they are what the workgroup's other
 // three waves are waiting for) and the linearProgram3 stragglers issue first, then pair phases in the order of the
 // step (a workgroup that is behind overtakes one that is ahead): 21.6 -> 20.3 us per step, rollout 14.1 -> 12.6
-// (profiles/r02_kernel_geometry.md; schemes 1-4 are the alternatives measured there, 0 = hardware default).
+// (profiles/r02_kernel_geometry.md).  PRIO(...) lists the level of a phase under schemes 1 .. 8 (-DCAGPU_PRIO=<n>; 0 =
+// hardware default): 1 agent wave 3 / ORCA pairs 2 / sensor pairs 1; 2 only linearProgram3 raised; 3 "earlier phase =
+// higher"; 4 agent wave 3, everything else 1; **5 = 1 with the emission phase and the post-linearProgram3 wait at 0 (the
+// product)**; 6 - 8 variations of 5 (sensor phases one level up; ORCA pairs at 3; emission at 1), all 0.05 - 0.3 us behind 5.
 #ifndef CAGPU_PRIO
 #define CAGPU_PRIO 5
 #endif
-#define PRIO(a, b, c, d, e) do { constexpr int pr_[6] = {0, a, b, c, d, e}; if (CAGPU_PRIO) __builtin_amdgcn_s_setprio(pr_[CAGPU_PRIO]); } while (0)
+#define PRIO(a, b, c, d, e, ...) do { constexpr int pr_[] = {0, a, b, c, d, e, __VA_ARGS__}; if (CAGPU_PRIO) __builtin_amdgcn_s_setprio(pr_[CAGPU_PRIO]); } while (0)
 // Pair items w = 0 .. n_items-1 are dealt to the NT threads in rounds; odd rounds run BACKWARDS over the threads, so the
 // last, partial round lands on the highest waves and wave 0 -- the agent wave -- is free for its one-lane-per-agent work
 // while the other waves finish the pair phase (400 items on 256 threads: wave 0 has one round, waves 2 and 3 two).
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   unsigned long long tprev_ = clock64();
 #endif
 #ifdef CAGPU_WGTIME
-  unsigned long long wg_t0 = 0, wg_info = 0;
+  unsigned long long wg_t0 = 0, wg_info = 0, wg_lp3 = 0;
   if (tid == 0) wg_t0 = wall_clock64();
 #endif
   // The phases are straight-line code in the single-step kernel (lambdas inlined at their call sites): with the
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       const uint32_t pol = (r.flags >> CA_POLICY_SHIFT) & 0xF;
       const bool query = active && !(r.flags & CA_DONE);  // env.py:311
       const bool rvo = query && pol == CA_POL_RVO;
-      if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(2, 0, 3, 1, 2);
+      if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3); else PRIO(2, 0, 3, 1, 2, 2, 3, 2);
       if (wave0) {
         ep_step += 1;  // env.py:183
         sh_fpx[lane] = static_cast<float>(r.px);
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       WG_SYNC();
       TICK(1);
       F2 v_orca = f2(0.f, 0.f);  // this lane's ORCA velocity (agent wave)
-      PRIO(2, 0, 3, 1, 2);
+      PRIO(2, 0, 3, 1, 2, 2, 3, 2);
       if (!AB(1)) {
         // ================= P2: every (querying agent, other) pair: neighbour rank (ascending distSq, ties by index:
         // Agent::insertAgentNeighbor) + ORCA half-plane
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           WG_SYNC();
           TICK(12);
           if (wave0 && rvo) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
-          if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(1, 0, 2, 0, 0);
+          if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3); else PRIO(1, 0, 2, 0, 0, 0, 0, 1);
         } else {
         // ================= P2b: linearProgram1 of EVERY line i against the lines before it, one thread per (agent, i).
         // The 1-D optimum on line i depends on the lines [0, i), the speed disc and the preferred velocity only -- not
@@ -827,7 +830,7 @@ LP1_UNROLL
         // ================= linearProgram2 = a scan over the lines, one lane per agent (agent wave); infeasible
         // programmes (4.6 % of the queries at N = 10) are queued for the cooperative linearProgram3 pass
         int failf = NOFAIL;
-        if (wave0) PRIO(3, 0, 3, 3, 3);
+        if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3);
         if (wave0 && rvo) {
           const int n = sh_nb[lane];
           const float radius = sh_fms[lane];
@@ -862,10 +865,13 @@ LP1_UNROLL
         // while N <= 16 (lane j = half-plane j; ballot + DPP row reductions), the whole wave beyond (cagpu_grouplp.inc)
         const int n3 = sh_q3[0];
 #ifdef CAGPU_WGTIME
-        if (tid == 0) wg_info = static_cast<unsigned long long>(n3) | (static_cast<unsigned long long>(sh_q3[ROW + 1]) << 8);
+        if (tid == 0) {
+          wg_info = static_cast<unsigned long long>(n3) | (static_cast<unsigned long long>(sh_q3[ROW + 1]) << 8);
+          wg_lp3 = wall_clock64();
+        }
 #endif
         if (n3 > 0 && !AB(2) && !EXP(8)) {  // workgroup-uniform (EXP(8): experiment, results invalid)
-          PRIO(3, 3, 3, 2, 3);
+          PRIO(3, 3, 3, 2, 3, 3, 3, 3);
           auto solve3 = [&](auto gs_tag) {
             constexpr int GS = decltype(gs_tag)::value;
             constexpr int GROUPS = NT / GS;
@@ -896,10 +902,13 @@ LP1_UNROLL
           }
           WG_SYNC();
           if (failf != NOFAIL) v_orca = f2(sh_vrx[lane], sh_vry[lane]);
-          if (wave0) PRIO(3, 0, 3, 3, 3); else PRIO(1, 0, 2, 0, 0);
+          if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3); else PRIO(1, 0, 2, 0, 0, 0, 0, 1);
         }
         }
       }
+#ifdef CAGPU_WGTIME
+      if (tid == 0) wg_lp3 = wall_clock64() - wg_lp3;  // the linearProgram3 pass (incl. its barrier), 10 ns ticks
+#endif
       TICK(3);
       // ================= A2c: policy post-processing (env.py:305-323) and move (agent.py:192-241), one lane per agent
       TICK(0);
@@ -1013,7 +1022,7 @@ LP1_UNROLL
 
       // ---- P3: every (agent, other) pair: centre distance -> collision gap, sensor key, p_orth
       //      (env.py:458-512; OtherAgentsStatesSensor.py:76-107)
-      PRIO(1, 0, 2, 1, 1);
+      PRIO(1, 0, 2, 1, 1, 2, 1, 1);
       if (NC != 0 && p.sort_mode != CA_SORT_TIME_TO_IMPACT) {
         // N compiled in: one item per UNORDERED pair {a, b} -- the float64 square root, the collision gap and the
         // horizon test are the same for both directions; only d - r_host - r_other (operand order) and p_orth (the
@@ -1108,7 +1117,7 @@ LP1_UNROLL
 
       TICK(7);
       // ---- P4: rank the candidates of every agent and emit its rows (OtherAgentsStatesSensor.py:20-55,109-143)
-      PRIO(1, 0, 1, 1, 0);
+      PRIO(1, 0, 1, 1, 0, 1, 0, 1);
       DUP(4096)
 #pragma unroll
       FOR_PAIR_ITEMS(w) {
@@ -1221,7 +1230,7 @@ LP1_UNROLL
       }
       // ---- A3 (wave 0, while the other waves finish the pair items of P4): rewards + collision flag (env.py:394-456),
       // observation scalars
-      if (wave0) PRIO(3, 0, 3, 3, 3);
+      if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3);
       if (wave0 && active) {
         if (k.mode == MODE_STEP && pass == 0) {
           double nearest = INFINITY;
@@ -1423,7 +1432,7 @@ LP1_UNROLL
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* o = g_wgtime + blockIdx.x * 8;
-    o[0] = wg_t0; o[1] = wg_t1; o[2] = wall_clock64(); o[3] = wg_info; o[4] = hw; o[5] = xcc;
+    o[0] = wg_t0; o[1] = wg_t1; o[2] = wall_clock64(); o[3] = wg_info; o[4] = hw; o[5] = xcc; o[6] = wg_lp3;
   }
 #endif
 }

@@ -55,6 +55,11 @@ for a in rows:
             m = (n3 >= lo) & (n3 <= hi)
             if m.any():
                 print("   %-10s %4d workgroups: duration mean %.2f p90 %.2f max %.2f" % (name, m.sum(), dur[m].mean(), np.percentile(dur[m], 90), dur[m].max()))
+        lp3 = a[:, 6] * tick
+        for lo, hi, name in ((0, 0, "n3 = 0"), (1, 1, "n3 = 1"), (2, 2, "n3 = 2"), (3, 4, "n3 = 3..4"), (5, 99, "n3 >= 5")):
+            m = (n3 >= lo) & (n3 <= hi)
+            if m.any():
+                print("   %-10s linearProgram3 pass: mean %.2f us p50 %.2f p90 %.2f max %.2f" % (name, lp3[m].mean(), np.percentile(lp3[m], 50), np.percentile(lp3[m], 90), lp3[m].max()))
         for v in (0, 1):
             m = rst == v
             if m.any():
