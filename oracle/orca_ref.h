@@ -160,6 +160,7 @@ struct LpStats {
   long queries, no_violation_at_start, lp1_calls, lp1_not_flagged_at_start, flagged_at_start, lines, infeasible;
   long hist_calls[16];
   long flagged_margin[8], surprise_margin[8], query_surprise_margin[8];  // the same with "nearly violated" lines flagged too
+  long has_infeasible_line, fail_at_first_infeasible, fail_elsewhere;  // 1-D programmes that are infeasible on their own
 };
 static const float kLpStatsMargins[8] = {0.0f, 0.02f, 0.05f, 0.1f, 0.2f, 0.3f, 0.5f, 1.0f};
 static LpStats g_lp_stats;
@@ -171,7 +172,7 @@ static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt,
   else res = opt;
 #ifdef ORCA_REF_STATS
   unsigned v0 = 0;
-  long calls = 0;
+  long calls = 0, first_inf = -1;
   unsigned vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (!dir_opt) {
     for (int k = 0; k < 8; ++k) {
@@ -181,6 +182,11 @@ static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt,
     }
     for (size_t i = 0; i < L.size(); ++i)
       if (cross(L[i].dir, sub(L[i].pt, res)) > 0.0f) v0 |= 1u << i;
+    for (size_t i = 0; i < L.size() && first_inf < 0; ++i) {  // first line violated at the start whose 1-D programme is infeasible
+      Vec tmp = res;
+      if (cross(L[i].dir, sub(L[i].pt, res)) > 0.0f && !lp1(L, i, radius, opt, false, tmp)) first_inf = static_cast<long>(i);
+    }
+    g_lp_stats.has_infeasible_line += (first_inf >= 0);
     g_lp_stats.queries += 1;
     g_lp_stats.lines += static_cast<long>(L.size());
     g_lp_stats.no_violation_at_start += (v0 == 0);
@@ -203,6 +209,8 @@ static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt,
         res = keep;
 #ifdef ORCA_REF_STATS
         if (!dir_opt) {
+          g_lp_stats.fail_at_first_infeasible += (static_cast<long>(i) == first_inf);
+          g_lp_stats.fail_elsewhere += (static_cast<long>(i) != first_inf);
           g_lp_stats.infeasible += 1;
           g_lp_stats.hist_calls[calls < 15 ? calls : 15] += 1;
           for (int k = 0; k < 8; ++k) g_lp_stats.query_surprise_margin[k] += sm[k];

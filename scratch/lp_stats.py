@@ -15,7 +15,7 @@ o.s['policy'][:] = orc.POL_RVO
 o.reset(table[np.arange(E) % 500])
 o.rollout(table, 400)   # steady state
 lib = C.CDLL('/tmp/libca_oracle_stats.so')
-buf = (C.c_long * 47)()
+buf = (C.c_long * 50)()
 lib.lp_stats(buf); a0 = np.array(buf[:])
 o.rollout(table, 400)
 lib.lp_stats(buf); a = np.array(buf[:]) - a0
@@ -27,3 +27,4 @@ print("infeasible %.4f" % (a[6] / q))
 print("hist of lp1 calls per query:", np.round(a[7:23] / q, 3))
 for k, m in enumerate([0.0, 0.02, 0.05, 0.1, 0.2, 0.3, 0.5, 1.0]):
     print("margin %.2f: flagged/query %.2f  surprise lines/query %.4f  queries with a surprise %.4f" % (m, a[23 + k] / q, a[31 + k] / q, a[39 + k] / q))
+print("queries with a 1-D programme that is infeasible on its own: %.4f; linearProgram2 fails AT the first such line: %.4f, at another line: %.4f" % (a[47] / q, a[48] / q, a[49] / q))
