@@ -156,8 +156,10 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--workload", choices=["rvo10", "ga3c20", "crowd50_laser"], default="rvo10")
-    ap.add_argument("--mode", choices=["step", "rollout"], default="step",
-                    help="step: one launch per env.step (the gym-compatible path); rollout: all K steps fused in one launch")
+    ap.add_argument("--mode", choices=["step", "graph", "rollout"], default="step",
+                    help="step: one launch per env.step, submitted call by call (the gym-compatible path); graph: the same "
+                         "K launches captured once into a HIP graph and replayed (one launch per env.step, no per-call "
+                         "submission); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-warm-seconds", type=float, default=0.3,
                     help="untimed steady-state warm-up on top of --warmup (launches until this much time has passed)")
@@ -210,8 +212,12 @@ def main():
     sim.set_fixture_table(table, env_id_offset=off, case_stride=stride)
     sim.reset_from_table()
 
+    graph = {}
+
     def run(n):
-        if a.mode == "rollout":
+        if a.mode == "graph" and n in graph:
+            graph[n].replay()
+        elif a.mode == "rollout":
             sim.rollout(n)
         elif a.workload == "crowd50_laser":
             for _ in range(n):
@@ -233,16 +239,24 @@ def main():
     reduce_episode_stats(sim.episode_stats(), world)
     run(a.warmup)
     torch.cuda.synchronize(dev)
+    if a.mode == "graph":  # capture the launches of K steps (and of the warm-up chunk) once; run() then replays them
+        for n in sorted({a.steps, 50}):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    sim.step() if a.workload != "crowd50_laser" else (sim.step(), sim.laserscan())
+            graph[n] = g
+        torch.cuda.synchronize(dev)
     gc.collect()
     gc.disable()
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < a.min_warm_seconds:
-        run(50 if a.mode == "step" else a.steps)
+        run(50 if a.mode in ("step", "graph") else a.steps)
         torch.cuda.synchronize(dev)
     # ---- timed: EXACTLY a.steps steps between barrier + synchronize on both sides; nothing else inside
     if world > 1:
         dist.barrier()
-        run(20 if a.mode == "step" else a.steps)   # the barrier idled the device: bring it back before the clock starts
+        run(20 if a.mode == "step" else (50 if a.mode == "graph" else a.steps))   # the barrier idled the device: bring it back before the clock starts
     torch.cuda.synchronize(dev)
     ev0.record()            # same stream the kernels are launched on (torch's current stream)
     t0 = time.perf_counter()
@@ -314,22 +328,40 @@ def main():
                 sh.reset_from_table()
                 halves.append(sh)
 
-            def run2(n):
-                for _ in range(n):
-                    for sh, st_ in zip(halves, streams):
-                        with torch.cuda.stream(st_):
+            # the launches of both chains are captured into ONE HIP graph (two parallel branches) and replayed: submitted
+            # call by call from Python, two launches per step are host-bound (~11 us each)
+            nrep = min(a.steps, 500)
+            for sh in halves:
+                for _ in range(max(a.warmup, 5)):
+                    sh.step()
+            torch.cuda.synchronize(dev)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                cur = torch.cuda.current_stream(dev)
+                for st_ in streams:
+                    st_.wait_stream(cur)
+                for sh, st_ in zip(halves, streams):
+                    with torch.cuda.stream(st_):
+                        for _ in range(nrep):
                             sh.step()
-            run2(a.warmup)
+                for st_ in streams:
+                    cur.wait_stream(st_)
+            g2.replay()
             torch.cuda.synchronize(dev)
-            t2 = time.perf_counter()
-            run2(a.steps)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(1, a.steps // nrep)
+            q0.record()
+            for _ in range(reps):
+                g2.replay()
+            q1.record()
             torch.cuda.synchronize(dev)
-            t2 = time.perf_counter() - t2
-            out["two_streams"] = {"value": E * N * a.steps / t2, "unit": "agent-steps/s", "ms_per_step": t2 * 1e3 / a.steps,
-                                  "launches_per_step": 2,
-                                  "note": "same workload as 2 x %d envs on 2 HIP streams, host wall clock; not the headline "
-                                          "(per-launch durations overlap, so the roofline above is quoted for the "
-                                          "single-stream launch)" % (E // 2)}
+            t2 = q0.elapsed_time(q1) * 1e-3
+            out["two_streams"] = {"value": E * N * nrep * reps / t2, "unit": "agent-steps/s",
+                                  "ms_per_step": t2 * 1e3 / (nrep * reps), "launches_per_step": 2,
+                                  "note": "same workload as 2 x %d envs: two chains of %d single-step launches each, as the "
+                                          "two branches of one HIP graph (the ramp-up and the tail of one chain's launch "
+                                          "overlap with the body of the other's); not the headline: per-launch durations "
+                                          "overlap, so the roofline above is quoted for the single-chain launch" % (E // 2, nrep)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "rvo10":
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))

@@ -61,6 +61,29 @@ float run(K kern, Arr s, int spin, int grid, int lds, int n) {
   return ms * 1e3f / n;
 }
 
+// the same empty kernel as a captured graph of n kernel nodes, replayed
+float run_graph(Arr s, int grid, int lds, int n, int reps) {
+  hipStream_t st;
+  hipStreamCreate(&st);
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_empty, dim3(grid), dim3(256), lds, st, s, 0);
+  hipStreamEndCapture(st, &g);
+  hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphLaunch(ge, st);
+  hipStreamSynchronize(st);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, st);
+  for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, st);
+  hipEventRecord(e1, st);
+  hipStreamSynchronize(st);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / (n * reps);
+}
+
 int main(int argc, char** argv) {
   const int grid = argc > 1 ? atoi(argv[1]) : 1024;
   const int lds = 24 * 1024;
@@ -68,6 +91,7 @@ int main(int argc, char** argv) {
   for (int q = 0; q < 16; ++q) { hipMalloc(&s.a[q], (size_t)grid * 40 * 8); hipMemset(s.a[q], 0, (size_t)grid * 40 * 8); }
   printf("grid %d x 256 threads, %d B LDS\n", grid, lds);
   printf("empty kernel              %.2f us / launch\n", run(k_empty, s, 0, grid, lds, 2000));
+  printf("empty kernel, graph of 200   %.2f us / kernel node\n", run_graph(s, grid, lds, 200, 10));
   printf("load 16 + store 9 arrays  %.2f us / launch\n", run(k_ldst, s, 0, grid, lds, 2000));
   for (int spin : {1000, 4000, -1000, -4000, -101000, -104000}) printf("  + %5d dependent FMAs (negative: f32) %.2f us / launch\n", spin, run(k_ldst, s, spin, grid, lds, 2000));
   return 0;
