@@ -9,15 +9,19 @@
 //   done / game over / fixture auto-reset + stats -> collision_avoidance_env.py:514-553, vec_env.py:120-128
 //
 // Mapping (wave64, no MFMA: this is branchy element-wise geometry): one WORKGROUP per tile of WHOLE
-// envs (floor(64 / num_agents) envs = up to 64 agents), so every neighbour an agent needs is owned by
-// the same workgroup and travels through LDS, never through HBM:
+// envs (floor(64 / num_agents) envs = up to 64 agents; 4 envs at the benchmark's 10 agents), so every neighbour an
+// agent needs is owned by the same workgroup and travels through LDS, never through HBM:
 //   * HBM loads/stores are agent-major SoA -> lane i touches element base+i: fully coalesced;
-//   * serial per-agent chains (incremental LP, float64 trig) run one LANE per agent on wave 0;
-//   * the O(N^2) pairwise work (ORCA half-planes, collision gaps, sensor keys/ranks/rows) runs one
-//     THREAD per ordered (agent, other) pair across all waves of the workgroup, reading the tile's
-//     positions / velocities / radii from LDS (same-agent threads hit the same address -> broadcast);
+//   * serial per-agent chains (the scan of the linear programme, float64 trig, rewards, flags) run one LANE per agent
+//     on wave 0, the tile's "agent wave";
+//   * the O(N^2) pairwise work (ORCA half-planes, the 1-D programmes of the linear programme, collision gaps, sensor
+//     keys / ranks / rows) runs one THREAD per (agent, other) -- or per (agent, line), or per unordered pair -- across
+//     all waves, reading the tile's positions / velocities / radii from LDS; where a wave holds whole agents the lanes
+//     of an agent exchange through ds_bpermute / DPP instead;
 //   * per-(agent, slot) work arrays live in LDS as [slot][agent] columns -> bank-conflict free;
-//   * the observation rows are staged in LDS and leave as one contiguous, coalesced block.
+//   * the observation rows go straight to HBM (or, for small launches, are staged in LDS and leave as one block).
+// A workgroup's step is a chain of dependent phases; the launch is latency-bound, not bandwidth-bound (DESIGN.md
+// section 4, profiles/r02_kernel_geometry.md): wave priorities, few barriers and short chains are what matter.
 // Envs never interact, so n-step rollouts need no grid-wide synchronisation.
 //
 // Numerics: float64 state in the reference's operation order, the action pair rounded to float32
