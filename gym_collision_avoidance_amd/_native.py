@@ -47,7 +47,7 @@ class CaOut(C.Structure):
 
 class CaAutoReset(C.Structure):
     _fields_ = [("table", _P), ("n_cases", C.c_int32), ("env_id_offset", C.c_int64), ("case_stride", C.c_int64),
-                ("reset_obs", _P)]
+                ("reset_obs", _P), ("heading_seed", C.c_uint64)]
 
 
 class CaMap(C.Structure):

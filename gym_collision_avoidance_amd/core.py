@@ -180,9 +180,11 @@ class BatchedSim(object):
                                                 self._stream()))
         return (out, status) if return_status else out
 
-    def set_fixture_table(self, table, env_id_offset=0, case_stride=None):
+    def set_fixture_table(self, table, env_id_offset=0, case_stride=None, heading_seed=0):
         """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,
-        test_cases.py:593-624): env e's k-th reset loads case (env_id_offset + e + k*case_stride) % C."""
+        test_cases.py:593-624): env e's k-th reset loads case (env_id_offset + e + k*case_stride) % C.
+        heading_seed != 0: training mode (test_cases.py:558-559) -- an auto-reset draws the initial heading uniformly in
+        [-pi, pi) on the device (Philox of seed, global env id, reset count, agent) instead of pointing at the goal."""
         self._fast_args = None
         if table is None:
             self._ar, self._table = None, None
@@ -200,7 +202,7 @@ class BatchedSim(object):
         torch.cuda.current_stream(self.device).synchronize()
         self._ar = nat.CaAutoReset(table=t.data_ptr(), n_cases=C_, env_id_offset=int(env_id_offset),
                                    case_stride=int(self.E if case_stride is None else case_stride),
-                                   reset_obs=self._reset_obs.data_ptr())
+                                   reset_obs=self._reset_obs.data_ptr(), heading_seed=int(heading_seed) & 0xFFFFFFFFFFFFFFFF)
 
     # ---------------------------------------------------------------- the C-ABI calls
     def reset(self, cases, headings=None, mask=None):

@@ -56,6 +56,7 @@ struct KArgs {
   int32_t n_cases;
   int64_t env_id_offset, case_stride;
   const float* reset_obs;  // [n_cases, N, W] reset observation of every case (nullptr: re-sense after an auto-reset)
+  unsigned long long heading_seed;  // != 0: random initial headings at an auto-reset (training mode)
   // explicit reset
   const double* reset_cases;
   const double* reset_headings;
@@ -1326,7 +1327,13 @@ LP1_UNROLL
             }
             reset_cnt += 1;
             const long c = (k.env_id_offset + e + static_cast<long>(reset_cnt) * k.case_stride) % k.n_cases;
-            reset_lane(r, k.table + (c * N + a) * 6, nullptr, p);
+            double h0 = 0.0;
+            if (k.heading_seed) {  // test_cases.py:558-559 (training mode): uniform in [-pi, pi)
+              const unsigned long long ge = static_cast<unsigned long long>(k.env_id_offset + e);
+              h0 = -kPi + kTwoPi * gen::uniform_at(k.heading_seed, static_cast<unsigned>(ge), static_cast<unsigned>(ge >> 32),
+                                                   static_cast<unsigned>(reset_cnt), static_cast<unsigned>(a));
+            }
+            reset_lane(r, k.table + (c * N + a) * 6, k.heading_seed ? &h0 : nullptr, p);
             ep_step = 0;
             statics_dirty = true;
             if (RO) {
@@ -1742,7 +1749,8 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
   if (ar) {
     if (!ar->table || ar->n_cases < 1) return fail(CA_EINVAL, "cagpu: bad CaAutoReset%s");
     k.table = ar->table; k.n_cases = ar->n_cases; k.env_id_offset = ar->env_id_offset; k.case_stride = ar->case_stride;
-    k.reset_obs = ar->reset_obs;
+    k.heading_seed = ar->heading_seed;
+    k.reset_obs = ar->heading_seed ? nullptr : ar->reset_obs;  // (a reset observation depends on the heading)
   }
   if (map && map->static_bits) {
     if (map->rows < 1 || map->cols < 1 || !(map->cell > 0.0)) return fail(CA_EINVAL, "cagpu: bad CaMap%s");

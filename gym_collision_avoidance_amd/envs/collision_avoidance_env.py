@@ -99,7 +99,8 @@ class CollisionAvoidanceEnv(Env):
         self._fixture = None
 
     def set_fixture_suite(self, num_agents, policies="RVO", agents_dynamics="unicycle", auto_reset=True,
-                          env_id_offset=0, case_stride=None, table=None, generate=None):
+                          env_id_offset=0, case_stride=None, table=None, generate=None, random_headings=None,
+                          heading_seed=1):
         """Batched evaluation on the reference's 500-case suite (run_full_test_suite.py:54-130): env e starts on case
         (env_id_offset + e) % 500 and, with auto_reset, its k-th episode loads case (env_id_offset + e + k*stride) % 500
         on the device (DummyVecEnv semantics, vec_env.py:120-128).
@@ -108,7 +109,10 @@ class CollisionAvoidanceEnv(Env):
         `generate`: dict(num_cases=..., seed=..., side_length=4.0 or (lo, hi), speed_bnds=(0.5, 2.0),
         radius_bnds=(0.2, 0.8)) -- the table is drawn ON THE DEVICE by cagpu_generate_cases (the reference's
         get_testcase_random, test_cases.py:212-253) when reset() builds the batch: training-mode resets then never touch
-        the host (initial headings point at the goal, as in EVALUATE_MODE)."""
+        the host.
+        `random_headings` (default: `not Config.EVALUATE_MODE`, the reference's rule, test_cases.py:553-559): initial
+        headings -- at reset() and at every on-device auto-reset -- are uniform in [-pi, pi) instead of pointing at the
+        goal; drawn on the device from `heading_seed`."""
         if generate is not None:
             assert table is None and int(generate["num_cases"]) >= 1 and "seed" in generate
             table = None
@@ -120,6 +124,8 @@ class CollisionAvoidanceEnv(Env):
             assert table.ndim == 3 and tuple(table.shape[1:]) == (num_agents, 6), table.shape
         self._fixture = dict(table=table, policies=policies, dynamics=agents_dynamics, auto_reset=auto_reset,
                              env_id_offset=env_id_offset, num_agents=num_agents, generate=generate,
+                             heading_seed=(int(heading_seed) or 1) if (random_headings if random_headings is not None
+                                                                      else not Config.EVALUATE_MODE) else 0,
                              case_stride=self.num_envs if case_stride is None else case_stride)
         self.default_agents = None
 
@@ -293,12 +299,18 @@ class CollisionAvoidanceEnv(Env):
             pol, dyn, isl, stl = self._plugin_ids(agents0)
             sim.set_plugins(np.array(pol)[None], np.array(dyn)[None], np.array(isl)[None], np.array(stl)[None])
             sim.set_fixture_table(f["table"] if f["auto_reset"] else None, env_id_offset=f["env_id_offset"],
-                                  case_stride=f["case_stride"])
+                                  case_stride=f["case_stride"], heading_seed=f["heading_seed"])
             idx = (np.arange(E) + f["env_id_offset"]) % len(f["table"])
             if hasattr(f["table"], "data_ptr"):
                 import torch
                 idx = torch.as_tensor(idx, device=f["table"].device)
-            sim.reset(f["table"][idx])
+            heads = None
+            if f["heading_seed"]:  # training mode: random initial headings (test_cases.py:558-559), drawn on the device
+                import torch
+                gen = torch.Generator(device=sim.device)
+                gen.manual_seed(f["heading_seed"])
+                heads = (torch.rand((E, N), generator=gen, device=sim.device, dtype=torch.float64) * 2.0 - 1.0) * np.pi
+            sim.reset(f["table"][idx], headings=heads)
             groups = [agents0]
         else:
             sim.set_fixture_table(None)

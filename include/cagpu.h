@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 3
+#define CAGPU_VERSION 4
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -135,6 +135,11 @@ typedef struct CaAutoReset {
   const float *reset_obs; /* device float [n_cases, N, 6+7*max_obs] or NULL: the reset observation of every case,
                              i.e. o->obs of cagpu_reset(num_envs = n_cases, cases = table) with the same CaParams.
                              With it an auto-reset copies the row; without it the tile runs a second sensing pass. */
+  uint64_t heading_seed;  /* 0: the initial heading of a reset agent points at its goal (EVALUATE_MODE, test_cases.py:555-557).
+                             Otherwise training mode (test_cases.py:558-559: np.random.uniform(-pi, pi)): heading =
+                             -pi + 2 pi u, u the Philox4x32-10 uniform of (heading_seed; global env id, reset count, agent)
+                             -- a pure function of those, whatever the batch size or sharding; reset_obs is then not
+                             used (the observation depends on the heading: second sensing pass). */
 } CaAutoReset;
 
 /* Static occupancy grid shared by every env (Map.py:6-24; the env builds Map(16 m, 16 m, 0.1 m), env.py:378-392).

@@ -1,12 +1,16 @@
 """GPU parity: the HIP path (through the C ABI, libcagpu.so) against the CPU oracle and the golden vectors
 recorded from the unmodified reference.  Bars (BASELINE.json north_star): collision / done masks bit-exact,
 positions / observations within 1e-5."""
+import os
+
 import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
 
 from tests import golden_util as gu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +78,7 @@ def _compare(o, g, tol=TOL, what=""):
 
 def test_library_loads_on_gpu():
     nat, core, orc = _mods()
-    assert nat.lib().cagpu_version() == 3
+    assert nat.lib().cagpu_version() == 4
     assert torch.cuda.is_available()
 
 
@@ -822,3 +826,46 @@ def test_device_scenarios_statistics_and_training_reset():
     torch.cuda.synchronize()
     st = g.episode_stats().cpu().numpy()
     assert st[0] > 100 and np.isfinite(g.obs.cpu().numpy()).all()
+
+
+def test_random_reset_headings_training_mode():
+    """CaAutoReset.heading_seed (test_cases.py:558-559, training mode): auto-resets draw the initial heading uniformly
+    in [-pi, pi) on the device; the observation handed back is that of the reset state (cagpu_observe reproduces it);
+    a heading is a function of (seed, global env id, reset count, agent) alone -- shards see what one big batch sees"""
+    nat, core, orc = _mods()
+    N, E = 10, 256
+    table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n10"]
+
+    def run(E_, off, seed, steps=260):
+        g = core.BatchedSim(core.make_params(E_, N))
+        g.set_plugins(nat.POL_RVO)
+        g.set_fixture_table(table, env_id_offset=off, case_stride=E, heading_seed=seed)
+        g.reset_from_table()
+        first = {}
+        prev = g.state["reset_count"].cpu().numpy().copy()
+        for t in range(steps):
+            g.step()
+            rc = g.state["reset_count"].cpu().numpy()
+            new = np.nonzero(rc != prev)[0]
+            if len(new):
+                hd = g.state["heading"].cpu().numpy()
+                obs = g.obs.cpu().numpy().copy()
+                ob2 = g.observe().cpu().numpy() if hasattr(g, "observe") else None
+                for e in new:
+                    first[(off + int(e), int(rc[e]))] = hd[e].copy()
+                if ob2 is not None:
+                    assert np.array_equal(ob2[new], obs[new])      # the reset observation IS the observation of the reset state
+            prev = rc.copy()
+        return first
+    a = run(E, 0, 7)
+    hs = np.array(list(a.values()))
+    assert len(a) > 200 and np.all((hs >= -np.pi) & (hs < np.pi))
+    assert abs(hs.mean()) < 0.15 and abs(hs.std() - np.pi / np.sqrt(3)) < 0.15           # uniform on [-pi, pi)
+    assert len(np.unique(np.round(hs.ravel(), 12))) > 0.99 * hs.size
+    b = run(E // 2, E // 2, 7)                                                              # the upper half as its own shard
+    common = [k for k in b if k in a]
+    assert len(common) > 50 and all(np.array_equal(a[k], b[k]) for k in common)
+    c = run(E, 0, 8, steps=200)
+    assert any(not np.array_equal(a[k], c[k]) for k in c if k in a)
+    goal = run(E, 0, 0, steps=200)                                                          # seed 0: towards the goal
+    assert len(goal) > 50

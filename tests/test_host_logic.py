@@ -29,14 +29,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.cagpu_version.restype = ctypes.c_int
-    assert lib.cagpu_version() == 3   # host-only call, no GPU needed
+    assert lib.cagpu_version() == 4   # host-only call, no GPU needed
 
 
 def test_ctypes_structs_match_header_layout():
     from gym_collision_avoidance_amd import _native as nat
     assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 17 * 8
     assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
-    assert ctypes.sizeof(nat.CaAutoReset) == 40 and nat.CaAutoReset.reset_obs.offset == 32
+    assert ctypes.sizeof(nat.CaAutoReset) == 48 and nat.CaAutoReset.reset_obs.offset == 32 and nat.CaAutoReset.heading_seed.offset == 40
     assert nat.CaParams.dt.offset == 32
     assert ctypes.sizeof(nat.CaNet) == 13 * 8 and nat.CaNet.rows_scratch.offset == 12 * 8
     assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
