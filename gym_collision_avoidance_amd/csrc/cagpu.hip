@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         }
         WG_SYNC();
         TICK(2);
-        if (NC == 0 && N > G16 && !EXP(32)) {
+        if (N > G16 && !EXP(32)) {
           // ================= more than 16 agents per env: one WAVE per querying agent solves the whole programme
           // cooperatively (lane j = line j): linearProgram2 as "first violated line" ballots with the 1-D programme of that
           // line solved by the lanes holding the lines before it, then linearProgram3 if it ends infeasible
@@ -1604,6 +1604,10 @@ int launch_main2(const KArgs& k, size_t total, hipStream_t st) {
       if (k.tile_envs == ROW / 10) return launch_main3<NT, STAGE, 10>(k, total, st);
       if (k.tile_envs == 4) return launch_main3<NT, STAGE, 10, 4>(k, total, st);
     }
+#ifndef CAGPU_FAST
+    if (k.p.num_agents == 20 && k.tile_envs == ROW / 20 && !knobs().no_nc)  // BASELINE config 3 (4096 x 20)
+      return launch_main3<NT, STAGE, 20>(k, total, st);
+#endif
   }
 #ifdef CAGPU_FAST  // scratch builds: only the N = 10 instantiations are compiled
   return fail(CA_EUNSUPPORTED, "cagpu: CAGPU_FAST experiment build supports num_agents == 10 only%s");
