@@ -862,6 +862,12 @@ def test_random_reset_headings_training_mode():
     assert len(a) > 200 and np.all((hs >= -np.pi) & (hs < np.pi))
     assert abs(hs.mean()) < 0.15 and abs(hs.std() - np.pi / np.sqrt(3)) < 0.15           # uniform on [-pi, pi)
     assert len(np.unique(np.round(hs.ravel(), 12))) > 0.99 * hs.size
+    from oracle.philox_ref import philox4x32_10                                             # the exact values
+    for (ge, rc), hd in list(a.items())[:40]:
+        for ag in range(N):
+            w = philox4x32_10((ge & 0xFFFFFFFF, ge >> 32, rc, ag), (7, 0))
+            u = ((w[0] >> 5) * 67108864.0 + (w[1] >> 6)) / 9007199254740992.0
+            assert hd[ag] == -np.pi + 2.0 * np.pi * u, (ge, rc, ag)
     b = run(E // 2, E // 2, 7)                                                              # the upper half as its own shard
     common = [k for k in b if k in a]
     assert len(common) > 50 and all(np.array_equal(a[k], b[k]) for k in common)
