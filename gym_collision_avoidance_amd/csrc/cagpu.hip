@@ -435,7 +435,13 @@ __device__ unsigned long long g_wgprof[1024 * 16];
 #else
 #define AB(bit) false
 #define DUP(bit)
+#if defined(CAGPU_WGTIME)
+// product-like build with one wall-clock stamp (100 MHz) per phase boundary on thread 0: g_wgphase[wg][slot] += elapsed
+__device__ unsigned int g_wgphase[4096 * 16];
+#define TICK(slot) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); wg_ph[slot] += static_cast<unsigned>(now_ - wg_prev); wg_prev = now_; } } while (0)
+#else
 #define TICK(slot) do {} while (0)
+#endif
 #endif
 #ifdef CAGPU_WGTIME  // experiment build: per-workgroup wall-clock stamps of the LAST launch (100 MHz counter), no timers inside
 __device__ unsigned long long g_wgtime[4096 * 8];
@@ -632,8 +638,9 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   unsigned long long tprev_ = clock64();
 #endif
 #ifdef CAGPU_WGTIME
-  unsigned long long wg_t0 = 0, wg_info = 0, wg_lp3 = 0;
-  if (tid == 0) wg_t0 = wall_clock64();
+  unsigned long long wg_t0 = 0, wg_info = 0, wg_lp3 = 0, wg_prev = 0;
+  unsigned wg_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid == 0) wg_t0 = wg_prev = wall_clock64();
 #endif
   // The phases are straight-line code in the single-step kernel (lambdas inlined at their call sites): with the
   // n-step loop and the two-pass sensing loop around them the register allocator keeps ~100 more VGPRs alive around
@@ -897,7 +904,15 @@ LP1_UNROLL
             for (int q3 = wv; q3 < n3; q3 += NT / 64) {
               const int ent = sh_q3[1 + q3], agf = ent & 0xFF, ff = (ent >> 8) & 0xFF;  // (bits 16 ..: the line count)
               F2 v = f2(sh_vrx[agf], sh_vry[agf]);
+#ifdef CAGPU_WGTIME
+              int it3 = 0;
+              TICK(13);  // (slot 13: barrier + queue / entry loads; slot 14: lp3_wave8 itself, wave 0's entries only)
+              lp3_wave8(Lmat + agf, CS, (ent >> 16) & 0xFF, ff, sh_fms[agf], v, tid & 63, &it3);
+              TICK(14);
+              if (tid == 0) wg_info += static_cast<unsigned long long>(it3) << 24;
+#else
               lp3_wave8(Lmat + agf, CS, (ent >> 16) & 0xFF, ff, sh_fms[agf], v, tid & 63);
+#endif
               if ((tid & 63) == 0) { sh_vrx[agf] = v.x; sh_vry[agf] = v.y; }
             }
           } else if (N <= G16) {
@@ -1444,6 +1459,8 @@ LP1_UNROLL
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* o = g_wgtime + blockIdx.x * 8;
     o[0] = wg_t0; o[1] = wg_t1; o[2] = wall_clock64(); o[3] = wg_info; o[4] = hw; o[5] = xcc; o[6] = wg_lp3;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g_wgphase[blockIdx.x * 16 + q] = wg_ph[q];
   }
 #endif
 }
@@ -1893,6 +1910,11 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
 int cagpu_debug_wgtime(unsigned long long* out) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtime), sizeof(unsigned long long) * 4096 * 8);
+  return 0;
+}
+int cagpu_debug_wgphase(unsigned int* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgphase), sizeof(unsigned int) * 4096 * 16);
   return 0;
 }
 #endif

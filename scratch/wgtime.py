@@ -73,3 +73,28 @@ print("20 launches: first start -> last end: mean %.2f us (min %.2f max %.2f); w
     np.mean(span_all), np.min(span_all), np.max(span_all), d.mean(), np.percentile(d, 50), np.percentile(d, 90), np.percentile(d, 99), np.percentile(d, 99.9)))
 print("the 10 workgroups that end last in each launch: n3 mean %.2f (all: %.2f), with a reset %.2f (all: %.2f), queries %.1f (all: %.1f)" % (
     np.mean(slow_n3), np.mean(all_n3), np.mean(slow_reset), np.mean(all_reset), np.mean(slow_live), np.mean(all_live)))
+
+# ---- phase boundaries of the last launch (10 ns stamps on thread 0 of every workgroup; slots as in prof_phases.py)
+SLOTS = {0: "entry / loads issued", 1: "A1 bodies + barrier", 2: "P2 rank, half-planes + barrier", 12: "P2b 1-D programmes + barrier",
+         15: "scan (wave 0) + queue + barrier", 3: "linearProgram3 pass", 13: "-", 14: "-", 4: "A2c: policy post (atan2, sqrt, clip)",
+         5: "A2c: move (sincos) + bookkeeping", 6: "publish + ego frame + barrier", 7: "P3 pair dist / keys + barrier",
+         8: "P4 round 1 + A3 (wave 0)", 9: "A4 prologue", 10: "A4 + barrier(or)", 11: "reset copy / end"}
+ph = (C.c_uint * (4096 * 16))()
+lib.cagpu_debug_wgphase(ph)
+P = np.frombuffer(ph, dtype=np.uint32).reshape(4096, 16)[:E // 4].astype(np.float64) * tick
+a = rows[-1]
+n3 = a[:, 3] & 0xFF
+light = n3 == 0
+print("phase (us)                                  all: mean  p90 |  n3 = 0: mean | n3 > 0: mean | slowest 1 %: mean")
+slow = np.argsort(P.sum(axis=1))[-max(len(P) // 100, 1):]
+for sl in (0, 1, 2, 12, 15, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+    c = P[:, sl]
+    print("  %-40s %5.2f %5.2f | %5.2f | %5.2f | %5.2f" % (SLOTS[sl], c.mean(), np.percentile(c, 90), c[light].mean(), c[~light].mean(), c[slow].mean()))
+print("  %-40s %5.2f" % ("sum", P.sum(axis=1).mean()))
+
+it3 = (a[:, 3] >> 24) & 0xFF   # outer iterations of the queue entries wave 0 solved (entry 0, 4, ...)
+for nit in (1, 2, 3, 4):
+    m = (it3 == nit) & (n3 >= 1) & (n3 <= 4)
+    if m.any():
+        print("  wave 0's linearProgram3 entry with %d outer iteration(s): %4d workgroups: setup %.2f us, lp3_wave8 %.2f us (p90 %.2f)" % (
+            nit, m.sum(), P[m, 13].mean(), P[m, 14].mean(), np.percentile(P[m, 14], 90)))
