@@ -640,7 +640,8 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
 #ifdef CAGPU_WGTIME
   unsigned long long wg_t0 = 0, wg_info = 0, wg_lp3 = 0, wg_prev = 0;
   unsigned wg_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid == 0) wg_t0 = wg_prev = wall_clock64();
+  unsigned long long wg_c0 = 0;
+  if (tid == 0) { wg_t0 = wg_prev = wall_clock64(); wg_c0 = clock64(); }
 #endif
   // The phases are straight-line code in the single-step kernel (lambdas inlined at their call sites): with the
   // n-step loop and the two-pass sensing loop around them the register allocator keeps ~100 more VGPRs alive around
@@ -1459,6 +1460,7 @@ LP1_UNROLL
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* o = g_wgtime + blockIdx.x * 8;
     o[0] = wg_t0; o[1] = wg_t1; o[2] = wall_clock64(); o[3] = wg_info; o[4] = hw; o[5] = xcc; o[6] = wg_lp3;
+    o[7] = clock64() - wg_c0;  // shader-clock cycles over the workgroup's life (against o[2] - o[0] at 100 MHz: the clock)
 #pragma unroll
     for (int q = 0; q < 16; ++q) g_wgphase[blockIdx.x * 16 + q] = wg_ph[q];
   }

@@ -98,3 +98,6 @@ for nit in (1, 2, 3, 4):
     if m.any():
         print("  wave 0's linearProgram3 entry with %d outer iteration(s): %4d workgroups: setup %.2f us, lp3_wave8 %.2f us (p90 %.2f)" % (
             nit, m.sum(), P[m, 13].mean(), P[m, 14].mean(), np.percentile(P[m, 14], 90)))
+
+cyc = a[:, 7].astype(np.float64); life = (a[:, 2] - a[:, 0]).astype(np.float64) * tick
+print("shader clock during the launch: %.0f MHz (clock64 cycles / wall-clock us over each workgroup's life, median)" % np.median(cyc / life))
