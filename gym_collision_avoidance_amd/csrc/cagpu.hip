@@ -85,9 +85,41 @@ __device__ __forceinline__ float sqf(float a) { return a * a; }
 // in this ROCm that intrinsic maps to the native (not correctly rounded) square root.
 __device__ __forceinline__ float divf(float a, float b) { return a / b; }
 __device__ __forceinline__ float sqrtf_rn(float a) { return sqrtf(a); }
+// The same two operations for the step kernel's ORCA phases: the compiler's correctly rounded sequences WITHOUT their range
+// handling (v_div_scale / v_div_fixup; the 2^32 rescaling and the class test of the square root) -- the same arithmetic
+// whenever no operand, intermediate or result is denormal, huge or NaN: 8 instead of 11 and 9 instead of 14 instructions,
+// all of them on dependent chains (linearProgram1 / 3 are chains of divisions).  scratch/divsqrt_check.hip: identical
+// bits on 2^28 random operands with exponents in [-60, 60] (division, reciprocal) / x in [2^-80, 2^80] (square root).
+// ORCA's operands are velocities, positions and their differences -- 0 (handled: 0 / b = 0, sqrt(0) = 0) or 1e-16 .. 1e8
+// in magnitude.  The stand-alone cagpu_orca kernel keeps the compiler's `/` and sqrtf for arbitrary inputs, and both
+// are held to the same oracle bit for bit (tests/test_gpu_parity.py).
+#if defined(CAGPU_EXP) && (CAGPU_EXP & 4)
+__device__ __forceinline__ float divq(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrtq(float a) { return sqrtf(a); }
+#else
+__device__ __forceinline__ float divq(float a, float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y, 1.0f);
+  y = __builtin_fmaf(e, y, y);
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ float sqrtq(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+  float o = (r_dn <= 0.0f) ? s_dn : s;
+  o = (r_up > 0.0f) ? s_up : o;
+  return (x == 0.0f) ? x : o;
+}
+#endif
 // RVO2's Vector2 / float: multiply by the reciprocal
 __device__ __forceinline__ F2 over(F2 a, float s) { const float inv = divf(1.0f, s); return f2(a.x * inv, a.y * inv); }
 __device__ __forceinline__ F2 unitf(F2 a) { return over(a, sqrtf_rn(dotf(a, a))); }
+__device__ __forceinline__ F2 unitq(F2 a) { const float inv = divq(1.0f, sqrtq(dotf(a, a))); return f2(a.x * inv, a.y * inv); }
 
 __device__ __forceinline__ double wrap_pi(double a) {  // util.py:141-146 ([-pi, pi))
   if (a >= kPi) a -= kTwoPi;   // first iteration of the reference's while loops, branch-free
@@ -275,8 +307,8 @@ __device__ __forceinline__ float4 half_plane_sel(F2 mpos, F2 mvel, float mrad, F
   const float w2 = dotf(w, w);
   const float dp1 = dotf(w, rp);
   const bool disc = !far || (dp1 < 0.0f && sqf(dp1) > R2 * w2);
-  const float sq = sqrtf_rn(disc ? w2 : (d2 - R2));  // |w|  or  the leg length
-  const float inv = divf(1.0f, disc ? sq : d2);
+  const float sq = sqrtq(disc ? w2 : (d2 - R2));  // |w|  or  the leg length
+  const float inv = divq(1.0f, disc ? sq : d2);
   // cut-off disc (and overlap)
   const F2 uw = f2(w.x * inv, w.y * inv);
   const F2 dir_a = f2(uw.y, -uw.x);
@@ -806,7 +838,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           const float dp = dotf(Pi, Di);
           const float disc = sqf(dp) + sqf(radius) - dotf(Pi, Pi);
           bool ok = !(disc < 0.0f);
-          const float sd = sqrtf_rn(ok ? disc : 0.0f);
+          const float sd = sqrtq(ok ? disc : 0.0f);
           float t_lo = -dp - sd;
           float t_hi = -dp + sd;
           auto against = [&](const int m) {  // intersect line i with line m (< i)
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             const float num = detf(Dm, Pi - Pm);
             const bool par = fabsf(den) <= kRvoEps;
             ok = ok && !(use && par && num < 0.0f);
-            const float tt = divf(num, par ? 1.0f : den);
+            const float tt = divq(num, par ? 1.0f : den);
             const float c_hi = (use && !par && den >= 0.0f) ? tt : INFINITY;
             const float c_lo = (use && !par && den < 0.0f) ? tt : -INFINITY;
             t_hi = (c_hi < t_hi) ? c_hi : t_hi;
@@ -849,7 +881,7 @@ LP1_UNROLL
           const float radius = sh_fms[lane];
           const F2 opt = f2(sh_fprx[lane], sh_fpry[lane]);
           F2 res = opt;
-          if (dotf(opt, opt) > sqf(radius)) res = radius * unitf(opt);
+          if (dotf(opt, opt) > sqf(radius)) res = radius * unitq(opt);
           for_n<8>(NC ? NC - 1 : n, [&](const int i) {
             // The loads do not depend on the running result, so all of them can be in flight before the select chain
             // starts -- provided the tests stay branch-free: the conditions are combined as integers (written with &&
