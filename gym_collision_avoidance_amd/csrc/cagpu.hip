@@ -116,6 +116,32 @@ __device__ __forceinline__ float sqrtq(float x) {
   return (x == 0.0f) ? x : o;
 }
 #endif
+// ... and for float64 (distances, preferred velocity, ego frame: UnicycleDynamics / Dynamics / the sensor): the compiler's
+// sequences are rsq + 9 multiply-adds (square root) and rcp + 2 Newton steps + one residual correction (divide); the range
+// handling around them (v_ldexp / v_cmp_class / v_div_scale / v_div_fixup) costs 8 and 3 more instructions per call.
+// scratch/divsqrt_check.hip: identical bits on 2^28 random operands with exponents in [-300, 300] / [-600, 600].
+#if defined(CAGPU_EXP) && (CAGPU_EXP & 4)
+__device__ __forceinline__ double divd(double a, double b) { return a / b; }
+__device__ __forceinline__ double sqrtd(double a) { return sqrt(a); }
+#else
+__device__ __forceinline__ double divd(double a, double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  const double q = a * y;
+  return __builtin_fma(__builtin_fma(-b, q, a), y, q);
+}
+__device__ __forceinline__ double sqrtd(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return (x == 0.0) ? x : g;
+}
+#endif
 // RVO2's Vector2 / float: multiply by the reciprocal
 __device__ __forceinline__ F2 over(F2 a, float s) { const float inv = divf(1.0f, s); return f2(a.x * inv, a.y * inv); }
 __device__ __forceinline__ F2 unitf(F2 a) { return over(a, sqrtf_rn(dotf(a, a))); }
@@ -376,10 +402,10 @@ struct Ego {
 __device__ __forceinline__ Ego ego_frame(double px, double py, double gx, double gy, double heading) {
   Ego e;
   const double dx = gx - px, dy = gy - py;
-  e.dist = sqrt(dx * dx + dy * dy);
+  e.dist = sqrtd(dx * dx + dy * dy);
   if (e.dist > 1e-8) {
-    e.prx = dx / e.dist;
-    e.pry = dy / e.dist;
+    e.prx = divd(dx, e.dist);
+    e.pry = divd(dy, e.dist);
   } else {
     e.prx = dx;
     e.pry = dy;
@@ -773,7 +799,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         }
         if (wave0 && rvo) {  // the preferred velocity (float64 sqrt + divide), while the other waves finish the pairs
           const double vx = r.gx - r.px, vy = r.gy - r.py;
-          const double sc = r.ps / sqrt(vx * vx + vy * vy);  // RVOPolicy.py:66-67
+          const double sc = divd(r.ps, sqrtd(vx * vx + vy * vy));  // RVOPolicy.py:66-67
           sh_fprx[lane] = static_cast<float>(sc * vx);
           sh_fpry[lane] = static_cast<float>(sc * vy);
           sh_fms[lane] = static_cast<float>(r.ps);
@@ -979,7 +1005,7 @@ LP1_UNROLL
             const double nh = (ang < 0.0) ? ang + kTwoPi : ((ang == 0.0) ? 0.0 : ang);  // `% (2*pi)`, :102
             dh = wrap_pi(nh - r.heading);
             TICK(14);
-            spd = k.inv_rvo_dt * sqrt(dpx * dpx + dpy * dpy);  // RVOPolicy.py:106: 1/self.dt * norm
+            spd = k.inv_rvo_dt * sqrtd(dpx * dpx + dpy * dpy);  // RVOPolicy.py:106: 1/self.dt * norm
             if (fabs(dh) > kPi / 6) {
               dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
               spd = 0.0;
@@ -1112,7 +1138,7 @@ LP1_UNROLL
           const double ax = sh_px[ga], ay = sh_py[ga], ar = sh_rad[ga];
           const double bx = sh_px[gb], by = sh_py[gb], br = sh_rad[gb];
           const double rx = bx - ax, ry = by - ay;  // other - host for host a; exactly negated for host b
-          const double d = sqrt(rx * rx + ry * ry);
+          const double d = sqrtd(rx * rx + ry * ry);
           int key_ab = KEY_NONE, key_ba = KEY_NONE;
           double po_ab = 0.0, po_ba = 0.0, d2_ab = 0.0, d2_ba = 0.0;
           if (!(d > p.sensing_horizon)) {
@@ -1148,7 +1174,7 @@ LP1_UNROLL
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag];
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
           const double rx = ox - hx, ry = oy - hy;
-          const double d = sqrt(rx * rx + ry * ry);
+          const double d = sqrtd(rx * rx + ry * ry);
           gap = d - (hr + orad);
           if (!(d > p.sensing_horizon)) {
             d2o = d - hr - orad;

@@ -24,6 +24,28 @@ __device__ __forceinline__ float sqrt_lean(float x) {
   o = (r_up > 0.0f) ? s_up : o;
   return (x == 0.0f) ? x : o;
 }
+__device__ __forceinline__ double divd(double a, double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  const double q = a * y;
+  return __builtin_fma(__builtin_fma(-b, q, a), y, q);
+}
+__device__ __forceinline__ double sqrtd(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return (x == 0.0) ? x : g;
+}
+__device__ __forceinline__ double mkd(uint32_t h, uint32_t h2, int elo, int ehi) {
+  const unsigned long long man = (static_cast<unsigned long long>(h & 0xFFFFFu) << 32) | h2, sgn = static_cast<unsigned long long>(h >> 31) << 63;
+  const unsigned long long ex = static_cast<unsigned long long>(elo + static_cast<int>((h >> 20) & 0x7FF) % (ehi - elo + 1) + 1023);
+  return __longlong_as_double(static_cast<long long>(sgn | (ex << 52) | man));
+}
 __device__ unsigned long long g_bad[4];
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 // operands: sign random, exponent uniform in [elo, ehi], mantissa random
@@ -42,6 +64,11 @@ __global__ void k(int elo, int ehi, unsigned seed) {
   if (__float_as_uint(q0) != __float_as_uint(q1)) atomicAdd(&g_bad[0], 1ull);
   if (__float_as_uint(s0) != __float_as_uint(s1)) atomicAdd(&g_bad[1], 1ull);
   if (__float_as_uint(r0) != __float_as_uint(r1)) atomicAdd(&g_bad[2], 1ull);
+  // float64: exponents 5 x as wide
+  const double da = mkd(mix(h2 + 1u), mix(h2 + 2u), 5 * elo, 5 * ehi), db = mkd(mix(h2 + 3u), mix(h2 + 4u), 5 * elo, 5 * ehi);
+  const double dx = fabs(mkd(mix(h2 + 5u), mix(h2 + 6u), 8 * elo, 8 * ehi > 1000 ? 1000 : 8 * ehi));
+  if (__double_as_longlong(da / db) != __double_as_longlong(divd(da, db))) atomicAdd(&g_bad[3], 1ull);
+  if (__double_as_longlong(sqrt(dx)) != __double_as_longlong(sqrtd(dx))) atomicAdd(&g_bad[3], 1ull << 32);
 }
 int main() {
   const int ranges[][2] = {{-20, 10}, {-40, 40}, {-60, 60}, {-126, 127}};
@@ -51,7 +78,8 @@ int main() {
     for (unsigned rep = 0; rep < 4; ++rep) hipLaunchKernelGGL(k, dim3(1 << 18), dim3(256), 0, 0, rg[0], rg[1], rep * 7919u + 1u);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bad), sizeof(h));
-    printf("exponents of a, b in [%4d, %3d] (2^28 cases): a / b differs %llu, sqrt differs %llu, 1 / b differs %llu\n", rg[0], rg[1], h[0], h[1], h[2]);
+    printf("exponents of a, b in [%4d, %3d] (2^28 cases): a / b differs %llu, sqrt differs %llu, 1 / b differs %llu | float64 (exponents x 5, sqrt x 8): divide differs %llu, sqrt differs %llu\n",
+           rg[0], rg[1], h[0], h[1], h[2], h[3] & 0xFFFFFFFFull, h[3] >> 32);
   }
   return 0;
 }
