@@ -459,6 +459,15 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
 
 #include "cagpu_grouplp.inc"
 
+// x / D for small non-negative x: with a compile-time D two full-rate instructions (24-bit multiply by ceil(2^20 / D),
+// shift; exact while x * D < 2^20), otherwise the float reciprocal form (convert, add, multiply, convert).  The remainder
+// x - q * D likewise takes the 24-bit multiply (v_mul_lo_u32 is a quarter-rate instruction).
+template <int D>
+__device__ __forceinline__ int div_small(const int x, const float inv_d) {
+  if (D > 0) return static_cast<int>(__umul24(static_cast<unsigned>(x), static_cast<unsigned>(((1 << 20) + (D > 0 ? D : 1) - 1) / (D > 0 ? D : 1))) >> 20);
+  return static_cast<int>((static_cast<float>(x) + 0.5f) * inv_d);
+}
+
 // for (q = 0; q < n; ++q) body(q) in blocks of BLK: with a run-time n (the generic kernel) the loads of a block are in
 // flight together instead of one LDS round trip per iteration (N = 50: the rank loop of the sensor took 57 k of the
 // step's 155 k cycles as a plain loop); with a compile-time n everything unrolls as before.
@@ -763,7 +772,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
         const float inv_gn = 1.0f / static_cast<float>(GN);
         const int apw = 64 / GN;     // agents per wave
         const int apr = NW * apw;    // agents per round of the workgroup
-        const int g = static_cast<int>((static_cast<float>(wl) + 0.5f) * inv_gn), jo = wl - g * GN;
+        const int g = div_small<(NC > 1 ? NC - 1 : NC)>(wl, inv_gn), jo = wl - __mul24(g, GN);
         const int gbase = (wl - jo) << 2;  // ds_bpermute byte address of the first lane of my agent's group
 #pragma unroll
         for (int c0 = 0; c0 < (NC ? tile_n : n_live); c0 += apr) {
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           const int c = c0 + wv * apw + g;
           const bool valid = (g < apw) && (c < n_live);
           const int ag = sh_q[valid ? c : 0];
-          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+          const int eb = __mul24(div_small<NC>(ag, inv_n), N), aa = ag - eb;
           const int j = jo + ((jo >= aa) ? 1 : 0);  // my other agent (index order is kept: ties by index)
           const F2 mpos = f2(sh_fpx[ag], sh_fpy[ag]);
           float dj = INFINITY;
@@ -1113,8 +1122,8 @@ LP1_UNROLL
 #pragma unroll
         FOR_ITEMS_UPTO(w, n_un) {
           if (AB(32)) continue;
-          const int le2 = static_cast<int>((static_cast<float>(w) + 0.5f) * (1.0f / static_cast<float>(PE)));
-          const int u = w - le2 * PE, eb = le2 * NN;
+          const int le2 = div_small<PE>(w, 1.0f / static_cast<float>(PE));
+          const int u = w - __mul24(le2, PE), eb = __mul24(le2, NN);
           if (!sh_sense[eb]) continue;  // sensing is decided per env
           if (u >= PE - NN) {  // self entry: never sensed, no gap
             const int a1 = u - (PE - NN);
@@ -1126,8 +1135,8 @@ LP1_UNROLL
           }
           int a1, b1;
           if (u < NN * HALF) {
-            const int sft = static_cast<int>((static_cast<float>(u) + 0.5f) * (1.0f / static_cast<float>(NN)));
-            a1 = u - sft * NN;
+            const int sft = div_small<NN>(u, 1.0f / static_cast<float>(NN));
+            a1 = u - __mul24(sft, NN);
             b1 = a1 + sft + 1;
             b1 -= (b1 >= NN) ? NN : 0;
           } else {
@@ -1164,10 +1173,10 @@ LP1_UNROLL
 #pragma unroll
       FOR_PAIR_ITEMS(w) {
         if (AB(32)) continue;
-        const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-        const int j = w - ag * N;
+        const int ag = div_small<NC>(w, inv_n);
+        const int j = w - __mul24(ag, N);
         if (!sh_sense[ag]) continue;
-        const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+        const int eb = __mul24(div_small<NC>(ag, inv_n), N), aa = ag - eb;
         int key = KEY_NONE;
         double po = 0.0, d2o = 0.0, gap = INFINITY;
         if (j != aa) {
@@ -1201,10 +1210,10 @@ LP1_UNROLL
 #pragma unroll
       FOR_PAIR_ITEMS(w) {
         if (AB(64)) continue;
-        const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-        const int j = w - ag * N;
+        const int ag = div_small<NC>(w, inv_n);
+        const int j = w - __mul24(ag, N);
         if (!sh_sense[ag]) continue;
-        const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N, aa = ag - eb;
+        const int eb = __mul24(div_small<NC>(ag, inv_n), N), aa = ag - eb;
         const int kj = kmat[j * CS + ag];
         const double oj = omat[j * CS + ag];
         int rank = 0, cnt = 0;
@@ -1276,12 +1285,12 @@ LP1_UNROLL
       if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
         WG_SYNC();
         FOR_PAIR_ITEMS(w) {
-          const int ag = static_cast<int>((static_cast<float>(w) + 0.5f) * inv_n);
-          const int j = w - ag * N;
+          const int ag = div_small<NC>(w, inv_n);
+          const int j = w - __mul24(ag, N);
           if (!sh_sense[ag]) continue;
           const int rank = rmat[j * CS + ag];
           if (rank >= N) continue;
-          const int eb = static_cast<int>((static_cast<float>(ag) + 0.5f) * inv_n) * N;
+          const int eb = __mul24(div_small<NC>(ag, inv_n), N);
           const int kj = kmat[j * CS + ag];
           const double oj = omat[j * CS + ag];
           int r2 = 0;
