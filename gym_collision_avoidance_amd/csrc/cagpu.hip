@@ -617,6 +617,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   const int ebase = active ? le * N : 0;
   const long i = e * N + a;
   const long tile_base = env0 * N;
+  float* const obs_tile = k.o.obs + tile_base * (6 + 7 * p.max_obs);  // the tile's observation rows (uniform: scalar arithmetic)
   long tile_cnt = static_cast<long>(p.num_envs) * N - tile_base;
   if (tile_cnt > tile_n) tile_cnt = tile_n;
 
@@ -1256,7 +1257,7 @@ LP1_UNROLL
           }
         }
         const int keep = cnt < p.obs_clip ? cnt : p.obs_clip;  // sensor :39
-        float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+        float* row = (STAGE ? sh_obs : obs_tile) + __mul24(ag, W);
         if (j == aa) row[1] = static_cast<float>(keep);  // num_other_agents_observed
         for (int sl = j; sl < K; sl += N)                // zero the unfilled rows (sensor :112)
           if (sl >= keep) {
@@ -1301,7 +1302,7 @@ LP1_UNROLL
             const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(rq < rank));
             r2 += static_cast<int>(rq < N) & (static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo));
           });
-          float* row = STAGE ? (sh_obs + static_cast<size_t>(ag) * W) : (k.o.obs + (tile_base + ag) * W);
+          float* row = (STAGE ? sh_obs : obs_tile) + __mul24(ag, W);
           const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
           const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
@@ -1353,7 +1354,7 @@ LP1_UNROLL
           sh_r2[lane] = r.t - r.slt;
         }
         if (do_sense) {
-          float* row = STAGE ? (sh_obs + static_cast<size_t>(lane) * W) : (k.o.obs + i * W);
+          float* row = (STAGE ? sh_obs : obs_tile) + __mul24(lane, W);
           row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
           row[2] = static_cast<float>(eg.dist);
           row[3] = static_cast<float>(eg.heading_ego);
