@@ -790,12 +790,26 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
             dj = dotf(d, d);
             if (!unlimited && !(dj < range_sq)) dj = INFINITY;
           }
-          int rank = 0, cnt = 0;
+          // rank = number of others that are closer (ties by index: they need two floats to be EQUAL -- symmetric starts --
+          // and are settled in a second walk by the waves that hold one)
+          int rank = 0, cnt = (N > 1) ? N - 1 : 0, tie = 0;
           for_n<8>(GN, [&](const int q) {
             const float dq = __int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj)));
-            rank += static_cast<int>(dq < dj) | (static_cast<int>(dq == dj) & static_cast<int>(q < jo));  // branch-free
-            cnt += static_cast<int>(dq < INFINITY);
+            rank += static_cast<int>(dq < dj);
+            tie += static_cast<int>(dq == dj);
           });
+          if (__any(tie > 1 && dj < INFINITY)) {  // (a distance always equals itself)
+            for_n<8>(GN, [&](const int q) {
+              const float dq = __int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj)));
+              rank += static_cast<int>(dq == dj) & static_cast<int>(q < jo);
+            });
+          }
+          if (!unlimited) {  // a finite neighborDist: count who is inside it
+            cnt = 0;
+            for_n<8>(GN, [&](const int q) {
+              cnt += static_cast<int>(__int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj))) < INFINITY);
+            });
+          }
           // (neighborDist = inf -- Config.SENSING_HORIZON, RVOPolicy.py:27 -- makes every other agent a neighbour)
           const int n = cnt < p.rvo_max_neighbors ? cnt : p.rvo_max_neighbors;
           if (valid) {
