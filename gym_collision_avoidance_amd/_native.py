@@ -13,6 +13,8 @@ CA_OK, CA_EINVAL, CA_EUNSUPPORTED, CA_ELAUNCH, CA_ENODEVICE = 0, -1, -2, -3, -4
 AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEARNING, STILL_LEARNING = (
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
+ABSENT, PLAN_VALID = 1 << 16, 1 << 17
+ABI_VERSION = 5   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -23,7 +25,7 @@ _P = C.c_void_p
 
 class CaParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_agents", "max_obs", "sort_mode", "game_over_mode",
-                                         "rvo_max_neighbors", "obs_clip", "reserved0")] + \
+                                         "rvo_max_neighbors", "obs_clip", "ragged")] + \
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
@@ -33,8 +35,8 @@ class CaParams(C.Structure):
 
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
                 "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
-                "reset_count", "env_stats")
-OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions")
+                "reset_count", "env_stats", "next_action")
+OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel")
 
 
 class CaState(C.Structure):
@@ -47,7 +49,7 @@ class CaOut(C.Structure):
 
 class CaAutoReset(C.Structure):
     _fields_ = [("table", _P), ("n_cases", C.c_int32), ("env_id_offset", C.c_int64), ("case_stride", C.c_int64),
-                ("reset_obs", _P), ("heading_seed", C.c_uint64)]
+                ("reset_obs", _P), ("reset_plan", _P), ("heading_seed", C.c_uint64)]
 
 
 class CaMap(C.Structure):
@@ -70,7 +72,7 @@ class CaNet(C.Structure):
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_plan")
 
 _lib = None
 
@@ -97,6 +99,7 @@ def lib():
     L.cagpu_step_map.argtypes = [PP, PS, PO, _P, PA, C.POINTER(CaMap), _P]
     L.cagpu_laserscan.argtypes = [PP, PS, C.POINTER(CaMap), C.POINTER(CaScan), _P]
     L.cagpu_observe.argtypes = [PP, PS, PO, _P]
+    L.cagpu_plan.argtypes = [PP, PS, _P]
     L.cagpu_orca.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int32,
                              C.c_float, _P, _P]
     L.cagpu_ga3c.argtypes = [PP, PS, _P, C.POINTER(CaNet), _P, _P, _P]
@@ -107,6 +110,10 @@ def lib():
             getattr(L, n).restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
     L.cagpu_last_kernel.restype = C.c_char_p
+    got = L.cagpu_version()
+    if got != ABI_VERSION:  # a stale or experiment build would silently mis-read the structs above
+        raise CagpuError("%s reports ABI version %d, this binding mirrors version %d of include/cagpu.h -- rebuild "
+                         "(python -m gym_collision_avoidance_amd.build_native)" % (LIB_PATH, got, ABI_VERSION))
     _lib = L
     return L
 

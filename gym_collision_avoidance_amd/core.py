@@ -25,12 +25,13 @@ def make_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, 
                 getting_close_range=0.2, sensing_horizon=math.inf, reward_at_goal=1.0, reward_collision=-0.25,
                 reward_time_step=0.0, reward_wiggly=0.0, wiggly_threshold=math.inf, reward_min=None, reward_max=None,
                 rvo_time_horizon=5.0, rvo_collab_coeff=0.5, max_heading_change=math.pi / 3, obs_clip=None,
-                reward_collision_wall=-0.25, rvo_dt=None):
+                reward_collision_wall=-0.25, rvo_dt=None, ragged=0):
     """CaParams with the reference's Config defaults (config.py:28-86) for an EvaluateConfig-style run."""
     p = nat.CaParams()
     p.num_envs, p.num_agents = int(num_envs), int(num_agents)
     p.max_obs = int(num_agents - 1 if max_obs is None else max_obs)
     p.obs_clip = p.max_obs if obs_clip is None else int(obs_clip)
+    p.ragged = int(ragged)   # envs may hold fewer than num_agents agents (case rows with radius <= 0 = empty slots)
     p.sort_mode, p.game_over_mode = int(sort_mode), int(game_over_mode)
     p.rvo_max_neighbors = int(num_agents if rvo_max_neighbors is None else rvo_max_neighbors)
     p.dt, p.near_goal_threshold, p.max_time_ratio = dt, near_goal_threshold, max_time_ratio
@@ -53,7 +54,11 @@ GA3C_DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 
 
 
 class BatchedSim(object):
-    def __init__(self, params, device="cuda:0", record_actions=False):
+    def __init__(self, params, device="cuda:0", record_actions=False, pipeline=True):
+        """pipeline: hand the kernels CaState.next_action (include/cagpu.h): the step kernel then computes the RVO policy of
+        the NEXT step beside the sensing half of this one and the next launch starts at the move -- bit-identical results.
+        Code that writes `state[...]` tensors directly must call invalidate_plan() afterwards (or overwrite `flags`
+        with words whose PLAN_VALID bit is clear); reset() does it by itself."""
         if not torch.cuda.is_available():
             raise nat.CagpuError("BatchedSim needs a ROCm device: the hot path is HIP-only (no CPU fallback)")
         self.lib = nat.lib()
@@ -70,15 +75,21 @@ class BatchedSim(object):
         self.state["episode_step"] = z((E,), torch.int32)
         self.state["reset_count"] = z((E,), torch.int32)
         self.state["env_stats"] = z((E, 8), torch.float64)
+        self.state["next_action"] = z((E, N, 4), torch.float32)
+        self.pipeline = bool(pipeline)
         self.obs = z((E, N, self.W), torch.float32)
         self.rewards = z((E, N), torch.float32)
         self.done = z((E, N), torch.uint8)
         self.game_over = z((E,), torch.uint8)
         self.actions = z((E, N, 2), torch.float32) if record_actions else None
+        self.orca_vel = z((E, N, 2), torch.float32) if record_actions else None
         self._cs = nat.CaState(**{n: self.state[n].data_ptr() for n in nat.STATE_FIELDS})
+        if not self.pipeline:
+            self._cs.next_action = None
         self._co = nat.CaOut(obs=self.obs.data_ptr(), rewards=self.rewards.data_ptr(), done=self.done.data_ptr(),
                              game_over=self.game_over.data_ptr(),
-                             actions=self.actions.data_ptr() if record_actions else None)
+                             actions=self.actions.data_ptr() if record_actions else None,
+                             orca_vel=self.orca_vel.data_ptr() if record_actions else None)
         self._ar = None
         self._fast_args = None    # prebuilt ctypes arguments of the external-action-free step (see step())
         self._table = None
@@ -104,6 +115,10 @@ class BatchedSim(object):
             t = t.to(self.device)
         return t.contiguous()
 
+    def invalidate_plan(self):
+        """Forget the pipelined policy query (CaState.next_action): call after writing state tensors directly."""
+        self.state["flags"].bitwise_and_(~nat.PLAN_VALID)
+
     # ---------------------------------------------------------------- configuration
     def set_plugins(self, policy, dynamics=None, is_learning=None, still_learning=None):
         """policy / dynamics: int ids (CA_POL_*, CA_DYN_*), broadcastable to [E,N].  The learning bits default to
@@ -117,7 +132,7 @@ class BatchedSim(object):
         bits = (pol << nat.POLICY_SHIFT) | (dyn << nat.DYNAMICS_SHIFT) | (isl * nat.IS_LEARNING) | \
                (stl * nat.STILL_LEARNING)
         cur = self.state["flags"]
-        cur.copy_((cur & 0x3F) | torch.as_tensor(bits.astype(np.int32), device=self.device))
+        cur.copy_((cur & (0x3F | nat.ABSENT)) | torch.as_tensor(bits.astype(np.int32), device=self.device))
         self._has_ga3c = bool((pol == nat.POL_GA3C_CADRL).any())
 
     def ga3c_rows(self):
@@ -196,13 +211,20 @@ class BatchedSim(object):
         C_ = int(t.shape[0])
         ps = nat.CaParams.from_buffer_copy(self.p)
         ps.num_envs = C_
-        scratch = BatchedSim(ps, device=self.device)
+        scratch = BatchedSim(ps, device=self.device, pipeline=self.pipeline)
         scratch.reset(t)
         self._reset_obs = scratch.obs
+        # ... and, for the pipelined step kernel, the first action of every case (CaAutoReset.reset_plan): an RVO agent's
+        # plan depends on positions / velocities / radii only, so the scratch batch may take every slot for an RVO agent
+        self._reset_plan = None
+        if self.pipeline and scratch.try_plan():
+            self._reset_plan = scratch.state["next_action"]
         torch.cuda.current_stream(self.device).synchronize()
         self._ar = nat.CaAutoReset(table=t.data_ptr(), n_cases=C_, env_id_offset=int(env_id_offset),
                                    case_stride=int(self.E if case_stride is None else case_stride),
-                                   reset_obs=self._reset_obs.data_ptr(), heading_seed=int(heading_seed) & 0xFFFFFFFFFFFFFFFF)
+                                   reset_obs=self._reset_obs.data_ptr(),
+                                   reset_plan=None if self._reset_plan is None else self._reset_plan.data_ptr(),
+                                   heading_seed=int(heading_seed) & 0xFFFFFFFFFFFFFFFF)
 
     # ---------------------------------------------------------------- the C-ABI calls
     def reset(self, cases, headings=None, mask=None):
@@ -306,6 +328,16 @@ class BatchedSim(object):
                                          self._stream()))
         self._keep = [e]
         return self.obs, self.rewards, self.game_over
+
+    def try_plan(self):
+        """cagpu_plan: the policy query of the next step ahead of time (fills state['next_action'], sets PLAN_VALID).
+        Returns False where the pipelined kernel has no instantiation for this batch (the step kernels then query the
+        policy at the start of the step, as without next_action)."""
+        rc = self.lib.cagpu_plan(C.byref(self.p), C.byref(self._cs), self._stream())
+        if rc == nat.CA_EUNSUPPORTED:
+            return False
+        nat.check(rc)
+        return True
 
     def observe(self):
         nat.check(self.lib.cagpu_observe(C.byref(self.p), C.byref(self._cs), C.byref(self._co), self._stream()))

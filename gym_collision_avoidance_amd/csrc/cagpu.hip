@@ -56,6 +56,7 @@ struct KArgs {
   int32_t n_cases;
   int64_t env_id_offset, case_stride;
   const float* reset_obs;  // [n_cases, N, W] reset observation of every case (nullptr: re-sense after an auto-reset)
+  const float* reset_plan; // [n_cases, N, 4] next_action of every case's reset state (pipelined kernel only)
   unsigned long long heading_seed;  // != 0: random initial headings at an auto-reset (training mode)
   // explicit reset
   const double* reset_cases;
@@ -492,6 +493,14 @@ __device__ __forceinline__ void for_n(const int n, F&& body) {
 // Everything the phases exchange lives in LDS; per-(agent, slot) arrays are [slot][ROW] columns so that a phase that
 // walks slots for a fixed agent (wave 0) and a phase that walks agents for a fixed slot both stay conflict-free.
 constexpr int ROW = 64;
+// Column stride of the per-(agent, slot) LDS tiles [slot][CS]: ODD, so that the lanes of one agent, which hold different
+// slots -- the half-plane store Lmat[rank * CS + agent] of the ORCA phase: a stride of 64 float4 put all nine of them on
+// the same four banks (SQ_LDS_BANK_CONFLICT 767 k cycles per launch at 4096 x 10, profiles/r02_rocprof_summary.md) --
+// spread over the banks, while lanes that walk agents for a fixed slot stay consecutive.
+#ifndef CAGPU_CSPAD
+#define CAGPU_CSPAD 1
+#endif
+constexpr int CS_ROW = ROW + CAGPU_CSPAD;
 constexpr int KEY_NONE = 2147483647;  // sort key of a pair that is not sensed (self, beyond the sensing horizon)
 #ifdef CAGPU_ABLATE  // experiment build (scratch/): run-time switches in k.ablate + in-kernel phase timers
 #define AB(bit) (k.ablate & (bit))
@@ -577,10 +586,13 @@ struct Lane {  // per-lane registers of one agent (wave 0)
 };
 
 // test_cases.py:545-557 + agent.py:59-138
-__device__ __forceinline__ void reset_lane(Lane& r, const double* c, const double* heading, const CaParams& p) {
+// (the heading travels by value: a pointer to a local kept a 16-byte scratch object alive in every instantiation)
+template <typename Params>  // (CaParams, or the pipelined kernel's address-space-qualified view of it)
+__device__ __forceinline__ void reset_lane(Lane& r, const double* c, const bool has_heading, const double heading,
+                                           const Params& p) {
   r.px = c[0]; r.py = c[1]; r.gx = c[2]; r.gy = c[3]; r.ps = c[4]; r.rad = c[5];
   r.vx = r.vy = 0.0;
-  r.heading = heading ? *heading : atan2(c[3] - c[1], c[2] - c[0]);
+  r.heading = has_heading ? heading : atan2(c[3] - c[1], c[2] - c[0]);
   const double dx = c[0] - c[2], dy = c[1] - c[3];
   r.slt = (sqrt(dx * dx + dy * dy) - p.near_goal_threshold) / c[4];
   double tr = p.max_time_ratio * r.slt;
@@ -590,7 +602,12 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const doubl
   r.epr = 0.0;
   r.act0 = r.act1 = 0.f;
   r.step_num = 0;
-  r.flags &= ~0x3Fu;
+  r.flags &= ~(0x3Fu | CA_ABSENT | CA_PLAN_VALID);
+  if (p.ragged && !(c[5] > 0.0)) {  // a padding row of a ragged table: the slot holds no agent in this episode
+    r.px = r.py = r.gx = r.gy = r.rad = r.heading = r.slt = r.tr = 0.0;
+    r.ps = 1.0;
+    r.flags |= CA_ABSENT | CA_DONE | CA_AT_GOAL | CA_WAS_AT_GOAL;
+  }
 }
 
 template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int TE = 0>
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   unsigned char* un = smem + lds_fixed_bytes(ROW);
   // Column stride of the per-(agent, slot) tiles: ROW = 64 (a shift) in general; for single-env tiles (N > 32) the N
   // columns actually used, which is what lets two 50-agent workgroups share a CU's LDS.
-  const int CS = NC ? ROW : k.col_stride;
+  const int CS = NC ? CS_ROW : k.col_stride;
   // ORCA view of the union
   float4* Lmat = reinterpret_cast<float4*>(un);                                          // [N-1][CS] half-planes
   float2* Rmat = reinterpret_cast<float2*>(Lmat + lds_orca_lines(N, CS));                // [N-1][CS] 1-D optimum on line i
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   if (k.mode == MODE_RESET) {
     do_sense = active && (!k.reset_mask || k.reset_mask[e]);
     if (do_sense) {
-      reset_lane(r, k.reset_cases + i * 6, k.reset_headings ? k.reset_headings + i : nullptr, p);
+      reset_lane(r, k.reset_cases + i * 6, k.reset_headings != nullptr, k.reset_headings ? k.reset_headings[i] : 0.0, p);
       ep_step = 0;
       reset_cnt = 0;
       statics_dirty = true;
@@ -737,7 +754,8 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
       if (wave0) PRIO(3, 0, 3, 3, 3, 3, 3, 3); else PRIO(2, 0, 3, 1, 2, 2, 3, 2);
       if (wave0) {
         ep_step += 1;  // env.py:183
-        sh_fpx[lane] = static_cast<float>(r.px);
+        // (an absent slot of a ragged batch sits at infinity: distSq = inf = "not a neighbour" for everybody)
+        sh_fpx[lane] = (p.ragged && (r.flags & CA_ABSENT)) ? INFINITY : static_cast<float>(r.px);
         sh_fpy[lane] = static_cast<float>(r.py);
         sh_fvx[lane] = static_cast<float>(r.vx);
         sh_fvy[lane] = static_cast<float>(r.vy);
@@ -804,7 +822,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
               rank += static_cast<int>(dq == dj) & static_cast<int>(q < jo);
             });
           }
-          if (!unlimited) {  // a finite neighborDist: count who is inside it
+          if (!unlimited || p.ragged) {  // a finite neighborDist / absent slots: count who is a neighbour
             cnt = 0;
             for_n<8>(GN, [&](const int q) {
               cnt += static_cast<int>(__int_as_float(__builtin_amdgcn_ds_bpermute(gbase + 4 * q, __float_as_int(dj))) < INFINITY);
@@ -1064,6 +1082,8 @@ LP1_UNROLL
         TICK(4);
         const float a0f = static_cast<float>(spd), a1f = static_cast<float>(dh);  // float32 `all_actions`
         if (active && k.o.actions) reinterpret_cast<float2*>(k.o.actions)[i] = make_float2(a0f, a1f);
+        if (active && k.o.orca_vel)  // parity hook: the velocity rvo2 chose for this agent (RVOPolicy.py:93), 0 if not queried
+          reinterpret_cast<float2*>(k.o.orca_vel)[i] = rvo ? make_float2(v_orca.x, v_orca.y) : make_float2(0.f, 0.f);
         if (active) {
           if (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) {
             if (r.flags & CA_AT_GOAL) r.flags |= CA_WAS_AT_GOAL;
@@ -1165,7 +1185,8 @@ LP1_UNROLL
           const double d = sqrtd(rx * rx + ry * ry);
           int key_ab = KEY_NONE, key_ba = KEY_NONE;
           double po_ab = 0.0, po_ba = 0.0, d2_ab = 0.0, d2_ba = 0.0;
-          if (!(d > p.sensing_horizon)) {
+          const bool both = !p.ragged || (ar > 0.0 && br > 0.0);  // (an absent slot of a ragged batch has radius 0)
+          if (both && !(d > p.sensing_horizon)) {
             d2_ab = d - ar - br;
             d2_ba = d - br - ar;
             // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100 (an integer: exact as int32)
@@ -1177,11 +1198,11 @@ LP1_UNROLL
           kmat[b1 * CS + ga] = key_ab;
           omat[b1 * CS + ga] = po_ab;
           d2mat[b1 * CS + ga] = static_cast<float>(d2_ab);
-          gmat[b1 * CS + ga] = d - (ar + br);
+          gmat[b1 * CS + ga] = both ? d - (ar + br) : INFINITY;
           kmat[a1 * CS + gb] = key_ba;
           omat[a1 * CS + gb] = po_ba;
           d2mat[a1 * CS + gb] = static_cast<float>(d2_ba);
-          gmat[a1 * CS + gb] = d - (br + ar);
+          gmat[a1 * CS + gb] = both ? d - (br + ar) : INFINITY;
         }
       } else {
       DUP(2048)
@@ -1199,8 +1220,9 @@ LP1_UNROLL
           const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
           const double rx = ox - hx, ry = oy - hy;
           const double d = sqrtd(rx * rx + ry * ry);
-          gap = d - (hr + orad);
-          if (!(d > p.sensing_horizon)) {
+          const bool both = !p.ragged || (hr > 0.0 && orad > 0.0);  // (an absent slot of a ragged batch has radius 0)
+          if (both) gap = d - (hr + orad);
+          if (both && !(d > p.sensing_horizon)) {
             d2o = d - hr - orad;
             // numpy scalar round(x, 2) bucket; ordering of k == ordering of k/100 (an integer: exact as int32)
             key = static_cast<int>(fmin(fmax(rint(d2o * 100.0), -2.0e9), 2.0e9));
@@ -1264,7 +1286,7 @@ LP1_UNROLL
                       (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j)));
             });
           }
-          if (p.sensing_horizon < INFINITY) {
+          if (p.sensing_horizon < INFINITY || p.ragged) {
             for_n<8>(N, [&](const int q) { cnt += static_cast<int>(kmat[q * CS + ag] != KEY_NONE); });
           } else {
             cnt = N - 1;  // every other agent of the env is sensed
@@ -1358,6 +1380,7 @@ LP1_UNROLL
             }
           }
           rw = fmin(fmax(rw, p.reward_min), p.reward_max);
+          if (p.ragged && (r.flags & CA_ABSENT)) rw = 0.0;  // no agent in this slot: the zero padding of wrappers.py:143-173
           r.epr += rw;
           reward = static_cast<float>(rw);
           const bool d = (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) != 0;
@@ -1369,10 +1392,11 @@ LP1_UNROLL
         }
         if (do_sense) {
           float* row = (STAGE ? sh_obs : obs_tile) + __mul24(lane, W);
-          row[0] = (r.flags & CA_IS_LEARNING) ? 1.f : 0.f;
-          row[2] = static_cast<float>(eg.dist);
-          row[3] = static_cast<float>(eg.heading_ego);
-          row[4] = static_cast<float>(r.ps);
+          const bool here = !(p.ragged && (r.flags & CA_ABSENT));
+          row[0] = (here && (r.flags & CA_IS_LEARNING)) ? 1.f : 0.f;
+          row[2] = here ? static_cast<float>(eg.dist) : 0.f;
+          row[3] = here ? static_cast<float>(eg.heading_ego) : 0.f;
+          row[4] = here ? static_cast<float>(r.ps) : 0.f;
           row[5] = static_cast<float>(r.rad);
         }
       }
@@ -1431,7 +1455,7 @@ LP1_UNROLL
               h0 = -kPi + kTwoPi * gen::uniform_at(k.heading_seed, static_cast<unsigned>(ge), static_cast<unsigned>(ge >> 32),
                                                    static_cast<unsigned>(reset_cnt), static_cast<unsigned>(a));
             }
-            reset_lane(r, k.table + (c * N + a) * 6, k.heading_seed ? &h0 : nullptr, p);
+            reset_lane(r, k.table + (c * N + a) * 6, k.heading_seed != 0, h0, p);
             ep_step = 0;
             statics_dirty = true;
             if (RO) {
@@ -1460,7 +1484,8 @@ LP1_UNROLL
           for (int q = tid; q < N * W; q += NT) {
             const int a2 = q / W, col = q - a2 * W;
             float v = src[q];
-            if (col == 0) v = (sh_flag[le2 * N + a2] & CA_IS_LEARNING) ? 1.f : 0.f;
+            if (col == 0)  // (is_learning comes from the live flags; the row of an absent slot is all zeros: radius 0)
+              v = ((sh_flag[le2 * N + a2] & CA_IS_LEARNING) && !(p.ragged && !(src[q + 5] > 0.f))) ? 1.f : 0.f;
             if (STAGE) sh_obs[base + q] = v;
             else k.o.obs[tile_base * W + base + q] = v;
           }
@@ -1531,7 +1556,7 @@ LP1_UNROLL
       ka->s.radius[i] = r.rad; ka->s.pref_speed[i] = r.ps; ka->s.slt[i] = r.slt;
     }
     reinterpret_cast<float2*>(ka->s.last_action)[i] = make_float2(r.act0, r.act1);
-    ka->s.flags[i] = r.flags;
+    ka->s.flags[i] = r.flags & ~static_cast<uint32_t>(CA_PLAN_VALID);  // (this kernel leaves no plan for the next step)
     ka->s.step_num[i] = r.step_num;
     if (a == 0) { ka->s.episode_step[e] = ep_step; ka->s.reset_count[e] = reset_cnt; }
   }
@@ -1548,6 +1573,8 @@ LP1_UNROLL
   }
 #endif
 }
+
+#include "cagpu_pipe.inc"
 
 // ---------------------------------------------------------------- stand-alone ORCA (rvo2 doStep replacement)
 struct OrcaArgs {
@@ -1771,6 +1798,35 @@ int launch_main(const KArgs& k, hipStream_t st) {
 #endif
 }
 
+// The software-pipelined kernel (cagpu_pipe.inc): the caller handed over CaState.next_action, the agent count has an
+// instantiation, the sensor sorts closest_first, an attached fixture table comes with its reset observations, and every
+// workgroup of the launch is resident at once (4 per CU).
+bool pipe_eligible(const KArgs& k) {
+  if (!k.s.next_action || k.p.num_agents != 10 || k.stage_obs) return false;
+  if (k.mode != MODE_STEP && k.mode != pipe::MODE_PLAN) return false;
+  if (k.p.sort_mode != CA_SORT_CLOSEST_FIRST) return false;
+  if (k.table && !k.reset_obs) return false;
+  return (static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * device_cus();
+}
+
+template <int NC, int TE, bool MULTI>
+int launch_pipe2(const KArgs& k, hipStream_t st) {
+  using G = pipe::Geo<NC, TE>;
+  static_assert(G::LDS <= 40 * 1024, "four workgroups per CU");
+  const unsigned grid = static_cast<unsigned>((k.p.num_envs + TE - 1) / TE);
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d", NC, TE,
+                MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode);
+  hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
+}
+
+int launch_pipe(const KArgs& k, hipStream_t st) {
+  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_pipe2<10, 4, true>(k, st);
+  return launch_pipe2<10, 4, false>(k, st);
+}
+
 // Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
 // single-step kernel (30.7 us; 128 -> 39, 384 / 512 -> 40) and the n-step rollout kernel (22.2 us / step; 128 -> 28.8).
 // The rollout kernel only reaches that since the build disables machine LICM (build_native.py): hoisted loop invariants
@@ -1779,8 +1835,12 @@ int launch_any(const KArgs& k0, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   KArgs k = k0;
   const int N = k.p.num_agents;
+#ifndef CAGPU_NOPIPE
+  if (pipe_eligible(k)) return launch_pipe(k, st);
+#endif
+  if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents == 10, closest_first sorting and at most 4 x CUs tiles%s");
   k.tile_envs = ROW / N;
-  k.col_stride = (N > 32) ? N : ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
+  k.col_stride = (N > 32) ? (CAGPU_CSPAD ? (N | 1) : N) : CS_ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
   // N = 10: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all co-resident, evenly
   // spread): 27.3 vs 30.9 us at 4096 envs, 23.3 vs 27.6 at 2048; beyond that the 6-env tile wins
   // (profiles/r01_kernel_geometry.md)
@@ -1856,6 +1916,7 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
     k.table = ar->table; k.n_cases = ar->n_cases; k.env_id_offset = ar->env_id_offset; k.case_stride = ar->case_stride;
     k.heading_seed = ar->heading_seed;
     k.reset_obs = ar->heading_seed ? nullptr : ar->reset_obs;  // (a reset observation depends on the heading)
+    k.reset_plan = ar->heading_seed ? nullptr : ar->reset_plan;
   }
   if (map && map->static_bits) {
     if (map->rows < 1 || map->cols < 1 || !(map->cell > 0.0)) return fail(CA_EINVAL, "cagpu: bad CaMap%s");
@@ -1978,6 +2039,22 @@ int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, 
 int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,
                   int32_t n_steps, void* stream) {
   return step_impl(p, s, o, ext_actions, ar, n_steps, stream);
+}
+
+int cagpu_plan(const CaParams* p, const CaState* s, void* stream) {
+  if (!p || !s) return fail(CA_EINVAL, "cagpu_plan: NULL params/state%s");
+  CaOut o;
+  std::memset(&o, 0, sizeof(o));
+  o.obs = reinterpret_cast<float*>(1); o.rewards = o.obs; o.done = reinterpret_cast<uint8_t*>(1); o.game_over = o.done;  // (not touched in this mode)
+  int rc = check_params(p, s, &o);
+  if (rc) return rc;
+  if (!s->next_action) return fail(CA_EINVAL, "cagpu_plan: CaState.next_action is NULL%s");
+  KArgs k;
+  std::memset(&k, 0, sizeof(k));
+  k.p = *p; k.s = *s;
+  k.n_steps = 1; k.mode = pipe::MODE_PLAN;
+  k.inv_rvo_dt = 1.0 / p->rvo_dt;
+  return launch_any(k, stream);
 }
 
 int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* stream) {

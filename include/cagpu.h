@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 4
+#define CAGPU_VERSION 5
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -48,7 +48,18 @@ enum {
   CA_IS_LEARNING = 1u << 6,
   CA_STILL_LEARNING = 1u << 7,
   CA_POLICY_SHIFT = 8,  /* 4 bits */
-  CA_DYNAMICS_SHIFT = 12 /* 4 bits */
+  CA_DYNAMICS_SHIFT = 12, /* 4 bits */
+  /* Ragged batches: this agent SLOT holds no agent in the env's current episode.  The reference draws the agent count per
+   * episode (test_cases.py:224-227: randint(2, MAX_NUM_AGENTS_IN_ENVIRONMENT + 1)) and every loop of its step runs over
+   * len(self.agents) (collision_avoidance_env.py:345-367); here num_agents is the batch-wide MAXIMUM and an env with fewer
+   * agents leaves its last slots absent.  Set by cagpu_reset / an auto-reset for a case row whose radius is <= 0 (the
+   * padding rows of a ragged table); an absent slot is no neighbour, no collision partner, is not sensed, does not count
+   * for game over or the episode statistics, and its outputs are zeros (observation row, reward) / done = 1 -- the zero
+   * padding of wrappers.py:143-173.  Absent slots carry CA_DONE | CA_AT_GOAL | CA_WAS_AT_GOAL as well. */
+  CA_ABSENT = 1u << 16,
+  /* CaState.next_action holds this agent's action for the NEXT step (software-pipelined policy, see next_action).
+   * Whoever writes the state arrays of an env directly must clear this bit for its agents (cagpu_reset does). */
+  CA_PLAN_VALID = 1u << 17
 };
 /* policy plugin ids (test_cases.py:68-85 `policy_dict`) */
 enum {
@@ -80,7 +91,8 @@ typedef struct CaParams {
   int32_t obs_clip;          /* OtherAgentsStatesSensor.max_num_other_agents_observed (<= max_obs): only the
                                 obs_clip closest others are emitted, the remaining rows stay zero
                                 (OtherAgentsStatesSensor.py:39,112) */
-  int32_t reserved0;
+  int32_t ragged;            /* != 0: envs may hold fewer than num_agents agents (CA_ABSENT slots: a case row with radius <= 0);
+                                0 = every slot holds an agent, whatever its radius (the kernels skip the absent-slot tests) */
   double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
   double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
   double reward_min, reward_max; /* np.clip bounds (collision_avoidance_env.py:589-599) */
@@ -110,6 +122,15 @@ typedef struct CaState {
   double *env_stats;           /* [E,8] episodes, collision eps, all-at-goal eps, stuck eps, sum steps,
                                   sum total_reward, sum time_to_goal, sum extra_time_to_goal
                                   (experiments/src/env_utils.py:56-87, reduced to counters) */
+  float *next_action;          /* [E*N,4] or NULL.  Software-pipelined policy query: the built-in RVO policy of step t+1
+                                  reads the post-move state of step t only (collision_avoidance_env.py:305-323 runs it
+                                  BEFORE anyone moves), exactly what the sensing / reward half of step t reads -- so with
+                                  this array a step computes both side by side on disjoint waves and stores, per agent,
+                                  {speed, delta heading (the float32 `all_actions` pair, env.py:305-307), ORCA velocity x, y}
+                                  for the next step, flagged CA_PLAN_VALID; the next cagpu_step / cagpu_rollout then
+                                  starts at the move.  Same arithmetic on the same inputs: results are bit-identical to
+                                  next_action == NULL.  Agents without a valid plan (after a reset, after the host wrote
+                                  the state, external / learning policies) are queried at the start of the step as before. */
 } CaState;
 
 /* Device pointers to what a step hands back (collision_avoidance_env.py:225-234). */
@@ -121,6 +142,10 @@ typedef struct CaOut {
   uint8_t *done;     /* [E,N] which_agents_done                         */
   uint8_t *game_over;/* [E]                                             */
   float *actions;    /* [E,N,2] the float32 `all_actions` array (env.py:305-307); may be NULL */
+  float *orca_vel;   /* [E,N,2] or NULL: for every agent whose RVOPolicy was queried in this step, the velocity rvo2 chose
+                        (PyRVOSimulator.doStep + getAgentVelocity, RVOPolicy.py:93) -- what cagpu_orca returns for the same
+                        float inputs, bit for bit; 0 for the agents that were not queried.  Parity hook for the ORCA phases of
+                        the step kernel itself. */
 } CaOut;
 
 /* Fixture-table auto-reset (the batched form of vec_env.py:120-128 + test_cases.py:593-624):
@@ -135,6 +160,9 @@ typedef struct CaAutoReset {
   const float *reset_obs; /* device float [n_cases, N, 6+7*max_obs] or NULL: the reset observation of every case,
                              i.e. o->obs of cagpu_reset(num_envs = n_cases, cases = table) with the same CaParams.
                              With it an auto-reset copies the row; without it the tile runs a second sensing pass. */
+  const float *reset_plan; /* device float [n_cases, N, 4] or NULL: CaState.next_action of every case's reset state (cagpu_plan
+                              on the state cagpu_reset(num_envs = n_cases, cases = table) leaves), so that an auto-reset
+                              env starts its new episode with a valid plan; only read when CaState.next_action is set. */
   uint64_t heading_seed;  /* 0: the initial heading of a reset agent points at its goal (EVALUATE_MODE, test_cases.py:555-557).
                              Otherwise training mode (test_cases.py:558-559: np.random.uniform(-pi, pi)): heading =
                              -pi + 2 pi u, u the Philox4x32-10 uniform of (heading_seed; global env id, reset count, agent)
@@ -186,8 +214,9 @@ const char *cagpu_last_kernel(void);
 /* Replaces: Agent.reset (agent.py:59-138) for every agent of the envs with mask[e] != 0 (mask NULL =
  * all), in the EVALUATE_MODE form of test_cases.py:545-590 (heading toward the goal unless
  * `headings` [E,N] is given), followed by the reset observation (collision_avoidance_env.py:276-282).
- * cases: device [E,N,6] = px, py, gx, gy, pref_speed, radius.  The policy / dynamics / learning bits
- * of `flags` must already be set; reset_count[e] is zeroed. */
+ * cases: device [E,N,6] = px, py, gx, gy, pref_speed, radius; a row with radius <= 0 leaves its slot absent
+ * (CA_ABSENT: ragged batches, absent slots last).  The policy / dynamics / learning bits of `flags` must already be
+ * set; reset_count[e] is zeroed, CA_PLAN_VALID cleared. */
 int cagpu_reset(const CaParams *p, const CaState *s, const CaOut *o, const double *cases, const double *headings,
                 const uint8_t *mask, void *stream);
 
@@ -243,6 +272,12 @@ int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, 
  * ext_actions (if any) are held constant over the n_steps. */
 int cagpu_rollout(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions,
                   const CaAutoReset *ar, int32_t n_steps, void *stream);
+
+/* The policy query of the NEXT step ahead of time (collision_avoidance_env.py:305-323 for the built-in RVO policy):
+ * fills s->next_action from the CURRENT state and sets CA_PLAN_VALID, without stepping.  cagpu_step / cagpu_rollout keep
+ * the plan up to date by themselves; this entry point exists for states that did not come out of a step (the reset state
+ * of a fixture table -> CaAutoReset.reset_plan).  Requires s->next_action and num_agents <= 10. */
+int cagpu_plan(const CaParams *p, const CaState *s, void *stream);
 
 /* Replaces: rvo2.PyRVOSimulator.doStep() + getAgentVelocity for every agent (call sites
  * RVOPolicy.py:25-28,70-74,86-93): one ORCA velocity per agent from C-float inputs.

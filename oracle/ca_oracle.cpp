@@ -75,6 +75,17 @@ struct Cand {
   double key, p_orth, tti;
 };
 
+// Ragged batches: the reference's env holds len(self.agents) <= MAX_NUM_AGENTS_IN_ENVIRONMENT agents and every loop of its
+// step runs over that list (env.py:345-367, test_cases.py:224-227); here an env is num_agents SLOTS and the slots without an
+// agent carry ORC_ABSENT.  `present` lists the slots that hold one, in slot (= list index) order.
+inline bool absent(const OrcParams& p, const OrcState& s, int i) { return p.ragged && (s.flags[i] & ORC_ABSENT); }
+inline std::vector<int> present(const OrcParams& p, const OrcState& s, int e) {
+  std::vector<int> v;
+  for (int a = 0; a < p.num_agents; ++a)
+    if (!absent(p, s, e * p.num_agents + a)) v.push_back(a);
+  return v;
+}
+
 // util.py:101-127 tangent_vecs_from_external_pt + util.py:23-83 compute_time_to_impact (float64, numpy order)
 inline double time_to_impact(double hx, double hy, double ox, double oy, double hvx, double hvy, double ovx, double ovy,
                              double r) {
@@ -120,12 +131,17 @@ inline double time_to_impact(double hx, double hy, double ox, double oy, double 
 void sense(const OrcParams& p, const OrcState& s, int e, int a, double* row) {
   const int N = p.num_agents, K = p.max_obs;
   const int base = e * N, h = base + a;
+  if (absent(p, s, h)) {  // no agent in this slot: the zero row of wrappers.py:143-173
+    std::memset(row, 0, sizeof(double) * (6 + 7 * K));
+    return;
+  }
   const Ego eg = ego_frame(s.pos_x[h], s.pos_y[h], s.goal_x[h], s.goal_y[h], s.heading[h]);
   std::vector<Cand> c;
   c.reserve(N);
   for (int j = 0; j < N; ++j) {
     if (j == a) continue;  // :79 (ids are the list indices in every builder of test_cases.py)
     const int o = base + j;
+    if (absent(p, s, o)) continue;
     const double rx = s.pos_x[o] - s.pos_x[h], ry = s.pos_y[o] - s.pos_y[h];
     const double p_orth = rx * eg.orth_x + ry * eg.orth_y;
     const double dc = std::sqrt(rx * rx + ry * ry);  // util.py:148-153
@@ -211,6 +227,11 @@ void reset_env(const OrcParams& p, const OrcState& s, int e, const double* cs /*
     s.last_action[2 * i] = s.last_action[2 * i + 1] = 0.f;
     s.step_num[i] = 0;
     s.flags[i] &= (ORC_IS_LEARNING | ORC_STILL_LEARNING);
+    if (p.ragged && !(c[5] > 0.0)) {  // padding row of a ragged table: an empty slot
+      s.pos_x[i] = s.pos_y[i] = s.goal_x[i] = s.goal_y[i] = s.radius[i] = s.heading[i] = s.slt[i] = s.time_remaining[i] = 0.0;
+      s.pref_speed[i] = 1.0;
+      s.flags[i] |= ORC_ABSENT | ORC_DONE | ORC_AT_GOAL | ORC_WAS_AT_GOAL;
+    }
   }
   s.episode_step[e] = 0;
 }
@@ -244,19 +265,22 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
   s.episode_step[e] += 1;  // env.py:183
 
   // ---- 1. actions from the PRE-step state (env.py:305-323) ----
-  std::vector<float> act(2 * N, 0.f);
+  std::vector<float> act(2 * N, 0.f), ovel(2 * N, 0.f);
   std::vector<orca_ref::Body> body;
   bool have_bodies = false;
-  for (int a = 0; a < N; ++a) {
+  const std::vector<int> P = present(p, s, e);  // the env's agent list
+  const int NP = static_cast<int>(P.size());
+  for (int ia = 0; ia < NP; ++ia) {
+    const int a = P[ia];
     const int i = b + a;
     if (s.flags[i] & ORC_DONE) continue;  // env.py:311
     double spd = 0.0, dh = 0.0;
     switch (s.policy[i]) {
       case ORC_POL_RVO: {  // policies/RVOPolicy.py:50-122
         if (!have_bodies) {  // :57-74 (identical for every ego agent of this env: same pre-step state)
-          body.resize(N);
-          for (int j = 0; j < N; ++j) {
-            const int q = b + j;
+          body.resize(NP);
+          for (int j = 0; j < NP; ++j) {
+            const int q = b + P[j];
             const double vx = s.goal_x[q] - s.pos_x[q], vy = s.goal_y[q] - s.pos_y[q];
             const double sc = s.pref_speed[q] / std::sqrt(vx * vx + vy * vy);  // :67
             body[j].pos = orca_ref::mk(static_cast<float>(s.pos_x[q]), static_cast<float>(s.pos_y[q]));
@@ -269,10 +293,12 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
           have_bodies = true;
         }
         const float ts = static_cast<float>(p.rvo_dt);  // RVOPolicy.py:13,26
-        const orca_ref::Vec v = orca_ref::new_velocity(body.data(), N, a, static_cast<float>(p.sensing_horizon),
+        const orca_ref::Vec v = orca_ref::new_velocity(body.data(), NP, ia, static_cast<float>(p.sensing_horizon),
                                                        static_cast<size_t>(p.rvo_max_neighbors),
                                                        static_cast<float>(p.rvo_time_horizon), ts);
-        const orca_ref::Vec np_ = orca_ref::advance(body[a].pos, v, ts);  // :93,:96
+        ovel[2 * a] = v.x;
+        ovel[2 * a + 1] = v.y;
+        const orca_ref::Vec np_ = orca_ref::advance(body[ia].pos, v, ts);  // :93,:96
         const double dpx = static_cast<double>(np_.x) - s.pos_x[i];       // :97 float32 pos - float64 pos
         const double dpy = static_cast<double>(np_.y) - s.pos_y[i];
         const double ang = std::atan2(dpy, dpx) - 0.0;                    // :100-101
@@ -317,9 +343,10 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
     act[2 * a + 1] = static_cast<float>(dh);
   }
   if (o.actions) std::memcpy(o.actions + 2 * b, act.data(), sizeof(float) * 2 * N);
+  if (o.orca_vel) std::memcpy(o.orca_vel + 2 * b, ovel.data(), sizeof(float) * 2 * N);
 
   // ---- 2. every agent moves (agent.py:192-241) ----
-  for (int a = 0; a < N; ++a) {
+  for (int a : P) {
     const int i = b + a;
     uint32_t f = s.flags[i];
     if (f & (ORC_AT_GOAL | ORC_OUT_OF_TIME | ORC_IN_COLLISION)) {  // :202-209
@@ -361,8 +388,9 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
   // ---- 3. all unordered pairs, done agents included (env.py:458-512) ----
   std::vector<uint8_t> coll(N, 0);
   std::vector<double> nearest(N, std::numeric_limits<double>::infinity());
-  for (int i = 0; i < N; ++i)
-    for (int j = i + 1; j < N; ++j) {
+  for (int ii = 0; ii < NP; ++ii)
+    for (int jj = ii + 1; jj < NP; ++jj) {
+      const int i = P[ii], j = P[jj];
       const double dx = s.pos_x[b + i] - s.pos_x[b + j], dy = s.pos_y[b + i] - s.pos_y[b + j];
       const double d = std::sqrt(dx * dx + dy * dy);  // util.py:17-21
       const double cr = s.radius[b + i] + s.radius[b + j];
@@ -372,7 +400,8 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
     }
 
   // ---- 4. rewards (env.py:394-456) ----
-  for (int a = 0; a < N; ++a) {
+  for (int a = 0; a < N; ++a) o.rewards[b + a] = 0.0;  // (empty slots)
+  for (int a : P) {
     const int i = b + a;
     uint32_t f = s.flags[i];
     double r = p.reward_time_step;
@@ -401,7 +430,8 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
 
   // ---- 6. done / game over (env.py:514-553) ----
   bool all_done = true, all_learning_done = true;
-  for (int a = 0; a < N; ++a) {
+  for (int a = 0; a < N; ++a) o.done[b + a] = 1;  // (empty slots)
+  for (int a : P) {
     const int i = b + a;
     uint32_t f = s.flags[i];
     const bool d = f & (ORC_AT_GOAL | ORC_OUT_OF_TIME | ORC_IN_COLLISION);
@@ -422,7 +452,7 @@ void episode_stats(const OrcParams& p, const OrcState& s, int e) {
   const int N = p.num_agents, b = e * N;
   bool any_coll = false, all_goal = true;
   double tot_r = 0.0, ttg = 0.0, extra = 0.0;
-  for (int a = 0; a < N; ++a) {
+  for (int a : present(p, s, e)) {
     const uint32_t f = s.flags[b + a];
     any_coll = any_coll || (f & ORC_IN_COLLISION);
     all_goal = all_goal && (f & ORC_AT_GOAL);
@@ -445,7 +475,7 @@ void episode_stats(const OrcParams& p, const OrcState& s, int e) {
 
 extern "C" {
 
-int ca_oracle_version(void) { return 1; }
+int ca_oracle_version(void) { return 2; }
 
 double ca_oracle_round2(double x) { return round2(x); }
 

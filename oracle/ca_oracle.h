@@ -28,7 +28,9 @@ enum {
   ORC_OUT_OF_TIME = 1u << 4,      /* agent.ran_out_of_time          (agent.py:238-239) */
   ORC_DONE = 1u << 5,             /* agent.is_done                  (env.py:534-535)   */
   ORC_IS_LEARNING = 1u << 6,      /* policy.str == "learning"       (config.py:152-157) */
-  ORC_STILL_LEARNING = 1u << 7    /* policy.is_still_learning       (Policy.py:13)     */
+  ORC_STILL_LEARNING = 1u << 7,   /* policy.is_still_learning       (Policy.py:13)     */
+  ORC_ABSENT = 1u << 16           /* ragged batches (OrcParams.ragged): this SLOT holds no agent in the env's episode -- the
+                                     reference's agent list is shorter than MAX_NUM_AGENTS_IN_ENVIRONMENT (test_cases.py:224-227) */
 };
 /* policy ids (test_cases.py:68-85 registry) */
 enum { ORC_POL_RVO = 0, ORC_POL_NONCOOP = 1, ORC_POL_STATIC = 2, ORC_POL_EXTERNAL = 3, ORC_POL_LEARNING = 4, ORC_POL_LEARNING_GA3C = 5,
@@ -42,7 +44,8 @@ enum { ORC_OVER_ALL_DONE = 0 /* EVALUATE_MODE */, ORC_OVER_AGENT0 = 1 /* TRAIN_S
 
 typedef struct {
   int32_t num_envs, num_agents, max_obs /* K: rows of the obs array */, sort_mode, game_over_mode, rvo_max_neighbors;
-  int32_t obs_clip /* sensor.max_num_other_agents_observed <= K */, reserved0;
+  int32_t obs_clip /* sensor.max_num_other_agents_observed <= K */;
+  int32_t ragged /* != 0: a reset row with radius <= 0 leaves its slot empty (ORC_ABSENT) */;
   double dt, near_goal_threshold, max_time_ratio, getting_close_range, sensing_horizon;
   double reward_at_goal, reward_collision, reward_time_step, reward_wiggly, wiggly_threshold;
   double reward_min, reward_max; /* np.clip bounds, env.py:589-599 */
@@ -71,6 +74,7 @@ typedef struct {
   uint8_t *done;     /* [E,N] which_agents_done */
   uint8_t *game_over;/* [E] */
   float *actions;    /* [E,N,2] the float32 all_actions array (debug / parity of the policy stage) */
+  float *orca_vel;   /* [E,N,2] or NULL: the velocity rvo2 chose for every agent whose RVOPolicy was queried (0 otherwise) */
 } OrcOut;
 
 /* Static map + LaserScanSensor (Map.py:6-64, sensors/LaserScanSensor.py:24-101; env.py:494-506 wall collisions).

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "_build", "libca_oracle.so")
 # flag bits / ids: mirror oracle/ca_oracle.h
 AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEARNING, STILL_LEARNING = (
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
+ABSENT = 1 << 16
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -29,7 +30,7 @@ _U8 = C.POINTER(C.c_uint8)
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_agents", "max_obs", "sort_mode", "game_over_mode",
-                                         "rvo_max_neighbors", "obs_clip", "reserved0")] + \
+                                         "rvo_max_neighbors", "obs_clip", "ragged")] + \
                [(n, C.c_double) for n in ("dt", "near_goal_threshold", "max_time_ratio", "getting_close_range",
                                           "sensing_horizon", "reward_at_goal", "reward_collision", "reward_time_step",
                                           "reward_wiggly", "wiggly_threshold", "reward_min", "reward_max",
@@ -48,7 +49,7 @@ class OrcState(C.Structure):
 
 
 class OrcOut(C.Structure):
-    _fields_ = [("obs", _D), ("rewards", _D), ("done", _U8), ("game_over", _U8), ("actions", _F)]
+    _fields_ = [("obs", _D), ("rewards", _D), ("done", _U8), ("game_over", _U8), ("actions", _F), ("orca_vel", _F)]
 
 
 class OrcMap(C.Structure):
@@ -82,12 +83,13 @@ def lib():
 
 def default_params(num_envs, num_agents, max_obs=None, dt=0.1, max_time_ratio=8.0, sort_mode=SORT_CLOSEST_FIRST,
                    game_over_mode=OVER_ALL_DONE, rvo_max_neighbors=None, near_goal=0.2, getting_close=0.2,
-                   obs_clip=None):
+                   obs_clip=None, ragged=0):
     """Constants of the reference Config (config.py:28-86) for an EvaluateConfig-style run (config.py:193-200)."""
     p = OrcParams()
     p.num_envs, p.num_agents = num_envs, num_agents
     p.max_obs = num_agents - 1 if max_obs is None else max_obs
     p.obs_clip = p.max_obs if obs_clip is None else obs_clip
+    p.ragged = int(ragged)
     p.sort_mode, p.game_over_mode = sort_mode, game_over_mode
     p.rvo_max_neighbors = num_agents if rvo_max_neighbors is None else rvo_max_neighbors
     p.dt, p.near_goal_threshold, p.max_time_ratio = dt, near_goal, max_time_ratio
@@ -126,6 +128,7 @@ class Oracle(object):
         self.done = np.zeros((E, N), np.uint8)
         self.game_over = np.zeros(E, np.uint8)
         self.actions = np.zeros((E, N, 2), np.float32)
+        self.orca_vel = np.zeros((E, N, 2), np.float32)
         self.cmap = None
         self.net = None           # oracle/ga3c_ref.GA3CNet, created on first use
         self.ga3c_index = None    # [E*N] last action indices chosen by the network (-1 = not queried)
@@ -137,7 +140,7 @@ class Oracle(object):
             setattr(st, n, _ptr(self.s[n], t))
         self.cs = st
         self.co = OrcOut(_ptr(self.obs, _D), _ptr(self.rewards, _D), _ptr(self.done, _U8), _ptr(self.game_over, _U8),
-                         _ptr(self.actions, _F))
+                         _ptr(self.actions, _F), _ptr(self.orca_vel, _F))
 
     def set_policies(self, policy, dynamics=None):
         pol = np.broadcast_to(np.asarray(policy, np.int32).reshape(-1, self.N) if np.ndim(policy) else policy,

@@ -63,3 +63,54 @@ def apply_constants(meta, *params):
         # collision_avoidance_env.py:589-599: clip bounds = min / max of the possible reward values
         vals = [p.reward_at_goal, p.reward_collision, p.reward_time_step, p.reward_collision_wall, p.reward_wiggly]
         p.reward_min, p.reward_max = min(vals), max(vals)
+
+
+# ---------------------------------------------------------------- the reference's full test suite (oracle/gen_suite_golden.py)
+def load_suite(name):
+    """tests/golden/suite_<name>.npz: one row per fixture case, recorded from the unmodified reference's run_episode
+    (experiments/src/env_utils.py:45-91 under run_full_test_suite.py:54-130)."""
+    with np.load(os.path.join(GOLD, "suite_%s.npz" % name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def suite_cases(name):
+    """The [500, N, 6] case table a suite ran on; `ragged4` pads the 2- and 3-agent cases with empty slots (radius 0)."""
+    if name == "ragged4":
+        out = np.zeros((500, 4, 6))
+        for c in range(500):
+            n = (2, 3, 4)[c % 3]
+            out[c, :n] = fixtures(n)[c]
+        return out
+    return fixtures(int(name[1:]))
+
+
+def run_suite(sim, cases, flags_of, step, max_steps=4000):
+    """Every case one env of `sim` (oracle or GPU batch, already reset on `cases`): step until every env has ended, latch
+    the reference's per-episode quantities at the step an env's game over first shows.  flags_of() -> uint32 [E,N];
+    step() -> (game_over [E] numpy, dict of numpy state arrays t / slt / ep_reward / pos_x / pos_y shaped [E,N])."""
+    E, N = cases.shape[:2]
+    out = dict(outcome=np.full(E, -1), steps=np.zeros(E, np.int64), time_to_goal=np.zeros((E, N)),
+               extra_time_to_goal=np.zeros((E, N)), total_reward=np.zeros((E, N)), flags=np.zeros((E, N), np.uint32),
+               pos=np.zeros((E, N, 2)))
+    live = np.ones(E, bool)
+    for t in range(1, max_steps + 1):
+        over, st = step()
+        ended = live & (over != 0)
+        if ended.any():
+            f = flags_of()
+            here = (f >> 16 & 1) == 0                      # slots that hold an agent
+            coll = ((f & 4) != 0) & here
+            goal = ((f & 1) != 0) | ~here
+            oc = np.where(coll.any(1), 0, np.where(goal.all(1), 1, 2))
+            out["outcome"][ended] = oc[ended]
+            out["steps"][ended] = t
+            out["time_to_goal"][ended] = (st["t"] * here)[ended]
+            out["extra_time_to_goal"][ended] = ((st["t"] - st["slt"]) * here)[ended]
+            out["total_reward"][ended] = (st["ep_reward"] * here)[ended]
+            out["flags"][ended] = ((f & 0x3F) * here)[ended]
+            out["pos"][ended] = (np.stack([st["pos_x"], st["pos_y"]], -1) * here[..., None])[ended]
+            live &= ~ended
+        if not live.any():
+            break
+    assert not live.any(), "%d episodes did not end" % live.sum()
+    return out

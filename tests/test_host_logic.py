@@ -29,14 +29,17 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.cagpu_version.restype = ctypes.c_int
-    assert lib.cagpu_version() == 4   # host-only call, no GPU needed
+    from gym_collision_avoidance_amd import _native as nat
+    assert lib.cagpu_version() == nat.ABI_VERSION == int(re.search(r"#define CAGPU_VERSION (\d+)", hdr).group(1))   # host-only call
 
 
 def test_ctypes_structs_match_header_layout():
     from gym_collision_avoidance_amd import _native as nat
     assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 17 * 8
-    assert ctypes.sizeof(nat.CaState) == 19 * 8 and ctypes.sizeof(nat.CaOut) == 5 * 8
-    assert ctypes.sizeof(nat.CaAutoReset) == 48 and nat.CaAutoReset.reset_obs.offset == 32 and nat.CaAutoReset.heading_seed.offset == 40
+    assert ctypes.sizeof(nat.CaState) == 20 * 8 and ctypes.sizeof(nat.CaOut) == 6 * 8
+    assert nat.CaState.next_action.offset == 19 * 8 and nat.CaOut.orca_vel.offset == 5 * 8 and nat.CaParams.ragged.offset == 28
+    assert ctypes.sizeof(nat.CaAutoReset) == 56 and nat.CaAutoReset.reset_obs.offset == 32
+    assert nat.CaAutoReset.reset_plan.offset == 40 and nat.CaAutoReset.heading_seed.offset == 48
     assert nat.CaParams.dt.offset == 32
     assert ctypes.sizeof(nat.CaNet) == 13 * 8 and nat.CaNet.rows_scratch.offset == 12 * 8
     assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
