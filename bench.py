@@ -161,6 +161,8 @@ def main():
                          "K launches captured once into a HIP graph and replayed (one launch per env.step, no per-call "
                          "submission); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="A/B: without CaState.next_action, i.e. the unpipelined step kernel (policy query at the start of the step)")
     ap.add_argument("--min-warm-seconds", type=float, default=0.3,
                     help="untimed steady-state warm-up on top of --warmup (launches until this much time has passed)")
     ap.add_argument("--no-extras", action="store_true",
@@ -198,7 +200,7 @@ def main():
     K = 19 if a.workload == "ga3c20" else N - 1
     table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
     sort = nat.SORT_CLOSEST_LAST if a.workload == "ga3c20" else nat.SORT_CLOSEST_FIRST
-    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort), device=dev)
+    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort), device=dev, pipeline=not a.no_pipeline)
     sim.set_plugins(nat.POL_GA3C_CADRL if a.workload == "ga3c20" else nat.POL_RVO, nat.DYN_UNICYCLE)
     if a.workload == "ga3c20":
         sim.load_ga3c()

@@ -400,6 +400,7 @@ class CollisionAvoidanceEnv(Env):
     def _write_agent(self, e, a, **fields):
         for name, v in fields.items():
             self._sim.state[name][e, a] = float(v)
+        self._sim.invalidate_plan()   # (a host write to the state: the pipelined policy query is forgotten)
         self._snap = None
 
     def _out(self, t):

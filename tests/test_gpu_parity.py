@@ -44,13 +44,27 @@ def _upload(o, g):
     for n in F64:
         g.state[n].copy_(torch.from_numpy(o.s[n].reshape(o.E, o.N)))
     g.state["last_action"].copy_(torch.from_numpy(o.s["last_action"].reshape(o.E, o.N, 2)))
-    fl = (o.s["flags"].astype(np.int64) & 0xFF) | (o.s["policy"].astype(np.int64) << nat.POLICY_SHIFT) | \
-         (o.s["dynamics"].astype(np.int64) << nat.DYNAMICS_SHIFT)
+    fl = (o.s["flags"].astype(np.int64) & (0xFF | orc.ABSENT)) | (o.s["policy"].astype(np.int64) << nat.POLICY_SHIFT) | \
+         (o.s["dynamics"].astype(np.int64) << nat.DYNAMICS_SHIFT)      # (PLAN_VALID clear: the plan is forgotten)
     g.state["flags"].copy_(torch.from_numpy(fl.astype(np.int32).reshape(o.E, o.N)))
     g.state["step_num"].copy_(torch.from_numpy(o.s["step_num"].reshape(o.E, o.N)))
     g.state["episode_step"].copy_(torch.from_numpy(o.s["episode_step"]))
     g.state["reset_count"].copy_(torch.from_numpy(o.s["reset_count"]))
     g.state["env_stats"].copy_(torch.from_numpy(o.s["env_stats"]))
+
+
+def _download(g, o):
+    """oracle state := GPU state (the reverse re-injection: both then continue from IDENTICAL bits)."""
+    nat, core, orc = _mods()
+    for n in F64:
+        o.s[n][:] = g.state[n].cpu().numpy().reshape(-1)
+    o.s["last_action"][:] = g.state["last_action"].cpu().numpy().reshape(o.s["last_action"].shape)
+    fl = g.state["flags"].cpu().numpy().reshape(-1).astype(np.uint32)
+    o.s["flags"][:] = (fl & 0xFF) | (fl & orc.ABSENT)
+    o.s["step_num"][:] = g.state["step_num"].cpu().numpy().reshape(-1)
+    o.s["episode_step"][:] = g.state["episode_step"].cpu().numpy()
+    o.s["reset_count"][:] = g.state["reset_count"].cpu().numpy()
+    o.s["env_stats"][:] = g.state["env_stats"].cpu().numpy()
 
 
 def _compare(o, g, tol=TOL, what=""):
@@ -274,10 +288,13 @@ def test_rollout_equals_repeated_steps(E, T):
 
 
 # ---------------------------------------------------------------- the metric geometry itself (4096 x 10 and its neighbours)
-def _expected_kernel(E, multi):
-    """the instantiation the launcher must pick on a 256-CU MI355X for N = 10 with precomputed reset observations:
+def _expected_kernel(E, multi, pipeline=True):
+    """the instantiation the launcher must pick on a 256-CU MI355X for N = 10 with precomputed reset observations: the
+    software-pipelined kernel (CaState.next_action given) while every workgroup is resident at once; otherwise
     4-env tiles while ceil(E / 4) <= 4 x CUs; the staged observation block only while <= 3 workgroups per CU"""
     wgs4 = (E + 3) // 4
+    if pipeline and wgs4 <= 4 * 256:
+        return "ca_pipe_kernel<10, 4, %s>" % ("true" if multi else "false")
     te = 4 if wgs4 <= 4 * 256 else 0
     wgs = wgs4 if te == 4 else (E + 5) // 6
     stage = wgs <= 3 * 256
@@ -346,9 +363,15 @@ def test_bench_kernel_is_the_tested_kernel():
     g.set_fixture_table(gu.fixtures(10))
     g.reset_from_table()
     g.step()
-    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<256, false, 10, false, true, 4> grid=1024")
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4, false> grid=1024")
     g.rollout(5)
-    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<256, false, 10, true, true, 4> grid=1024")
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4, true> grid=1024")
+    h = core.BatchedSim(core.make_params(4096, 10), pipeline=False)     # without next_action: the round-2 kernel
+    h.set_plugins(nat.POL_RVO)
+    h.set_fixture_table(gu.fixtures(10))
+    h.reset_from_table()
+    h.step()
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<256, false, 10, false, true, 4> grid=1024")
 
 
 # ---------------------------------------------------------------- ORCA stage alone (rvo2 replacement)
@@ -875,3 +898,192 @@ def test_random_reset_headings_training_mode():
     assert any(not np.array_equal(a[k], c[k]) for k in c if k in a)
     goal = run(E, 0, 0, steps=200)                                                          # seed 0: towards the goal
     assert len(goal) > 50
+
+
+# ---------------------------------------------------------------- round 3: the ORCA phases of the STEP kernels bit for bit
+def _state_bits(g):
+    out = {n: g.state[n].cpu().numpy().copy() for n in F64 + ("last_action", "step_num", "episode_step", "reset_count",
+                                                              "env_stats")}
+    out["flags"] = g.state["flags"].cpu().numpy() & ~(1 << 17)           # (PLAN_VALID is bookkeeping, not state)
+    for n in ("obs", "rewards", "done", "game_over", "actions", "orca_vel"):
+        out[n] = getattr(g, n).cpu().numpy().copy()
+    return out
+
+
+def _assert_same_bits(a, b, what):
+    for n in a:
+        x, y = a[n], b[n]
+        same = np.array_equal(x.view(np.uint8) if x.dtype.kind == "f" else x, y.view(np.uint8) if y.dtype.kind == "f" else y)
+        assert same, "%s differs (%s): %d of %d elements" % (n, what, (x != y).sum(), x.size)
+
+
+@pytest.mark.parametrize("N,E,steps,pipeline", [(10, 3073, 12, True), (10, 4096, 12, True), (10, 4096, 12, False),
+                                                (10, 5200, 8, True), (20, 300, 12, True), (50, 40, 10, True),
+                                                (4, 333, 12, True)])
+def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
+    """CaOut.orca_vel -- the velocity the ORCA phases of the STEP kernel itself chose (branch-free half-planes, divq /
+    sqrtq, parallel 1-D programmes + scan, lp3_wave8 / lp3_group / the wave-per-agent programme of N > 16; in the
+    pipelined kernel the plan computed beside the previous step's sensing half) -- against the oracle's RVO2 restatement,
+    bit for bit, on mid-episode states.  GPU and oracle continue from IDENTICAL bits each step (the GPU state is copied
+    into the oracle), so every float input of ORCA is the same on both sides and the pipelined kernel stays on its fast
+    path: the velocities compared at step t+1 were planned during launch t."""
+    nat, core, orc = _mods()
+    table = gu.fixtures(N)
+    po, pg = orc.default_params(E, N), core.make_params(E, N)
+    o, g = orc.Oracle(po), core.BatchedSim(pg, record_actions=True, pipeline=pipeline)
+    o.s["policy"][:] = orc.POL_RVO
+    g.set_plugins(nat.POL_RVO)
+    cases = table[np.arange(E) % table.shape[0]]
+    o.reset(cases)
+    for _ in range(60 if N <= 10 else 25):           # mid-episode: most programmes have violated lines, some infeasible
+        o.step()
+    _upload(o, g)
+    queried = 0
+    for t in range(steps):
+        _download(g, o)
+        was_done = (o.s["flags"] & orc.DONE) != 0
+        o.step()
+        g.step()
+        kern = nat.lib().cagpu_last_kernel().decode()
+        if N == 10 and pipeline and E <= 4096:
+            assert kern.startswith("ca_pipe_kernel<10, 4, false>"), kern
+            if t > 0:   # the fast path: every agent that is queried next holds a valid plan
+                assert (g.state["flags"].cpu().numpy().reshape(-1) >> 17 & 1).all()
+        else:
+            assert kern.startswith("ca_kernel<"), kern
+        got, want = g.orca_vel.cpu().numpy().reshape(-1, 2), o.orca_vel.reshape(-1, 2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+            "step %d: %d of %d ORCA velocities differ (max %g)" % (t, (got != want).any(1).sum(), (~was_done).sum(),
+                                                                   np.abs(got - want).max())
+        assert not g.actions.cpu().numpy().reshape(-1, 2)[was_done].any()
+        queried += int((~was_done).sum())
+        _compare(o, g, what="N=%d step %d" % (N, t))
+    assert queried > E * N * steps // 4
+
+
+@pytest.mark.parametrize("E,chunks", [(100, [1] * 40 + [7, 1, 1, 30, 2, 150]), (4096, [1] * 6 + [5, 1, 40, 1, 1])])
+def test_pipelined_equals_unpipelined_bit_for_bit(E, chunks):
+    """CaState.next_action changes WHEN the RVO policy of a step is computed (beside the previous step's sensing half
+    instead of at the start of the step), never what it computes: state and outputs of a free run with auto-resets --
+    single steps and fused rollouts mixed, the plan crossing launch boundaries -- are identical bit for bit."""
+    nat, core, orc = _mods()
+    N = 10
+    table = gu.fixtures(N)
+    sims = []
+    for pl in (True, False):
+        g = core.BatchedSim(core.make_params(E, N), record_actions=True, pipeline=pl)
+        g.set_plugins(nat.POL_RVO)
+        g.set_fixture_table(table)
+        g.reset_from_table()
+        sims.append(g)
+    a, b = sims
+    a.rollout(130)
+    b.rollout(130)          # mid-episode, first auto-resets behind us
+    t = 130
+    for n in chunks:
+        for g in sims:
+            g.step() if n == 1 else g.rollout(n)
+        t += n
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<")      # (b ran last)
+        _assert_same_bits(_state_bits(a), _state_bits(b), "after %d steps" % t)
+    assert a.episode_stats()[0].item() > E // 2
+    # a host write to the state without invalidate_plan() would leave a stale plan: the documented remedy works
+    for g in sims:
+        g.state["pos_x"].add_(0.01)
+        g.invalidate_plan()
+        g.step()
+    _assert_same_bits(_state_bits(a), _state_bits(b), "after a host write")
+
+
+def test_pipelined_kernel_mixed_policies_and_plan_entry_point():
+    """non-RVO agents (external learner, non-cooperative, static) inside pipelined tiles; cagpu_plan on a reset state
+    gives the plan the first step would compute"""
+    nat, core, orc = _mods()
+    N, E = 10, 64
+    table = gu.fixtures(N)
+    rng = np.random.default_rng(3)
+    pol = rng.choice([nat.POL_RVO, nat.POL_RVO, nat.POL_NONCOOP, nat.POL_STATIC, nat.POL_LEARNING], size=(E, N))
+    ext = rng.uniform(0, 1, (E, N, 2))
+    sims = []
+    for pl in (True, False):
+        g = core.BatchedSim(core.make_params(E, N, game_over_mode=nat.OVER_ALL_DONE), record_actions=True, pipeline=pl)
+        g.set_plugins(pol)
+        g.set_fixture_table(table)
+        g.reset_from_table()
+        sims.append(g)
+    a, b = sims
+    assert a.try_plan()
+    assert (a.state["flags"].cpu().numpy() >> 17 & 1).all()
+    plan0 = a.state["next_action"].cpu().numpy().copy()
+    for t in range(120):
+        for g in sims:
+            g.step(ext)
+        if t == 0:
+            rvo = pol == nat.POL_RVO
+            assert np.array_equal(a.actions.cpu().numpy()[rvo], plan0[..., :2][rvo])      # the plan WAS the first action
+        _assert_same_bits(_state_bits(a), _state_bits(b), "mixed policies, step %d" % t)
+
+
+# ---------------------------------------------------------------- round 3: the reference's own full test suite on the GPU
+@pytest.mark.parametrize("name", ["n10", "n4", "ragged4"])
+def test_reference_suite_outcomes(name):
+    """tests/golden/suite_*.npz: the unmodified reference's run_episode rows for 500 fixture cases (oracle/gen_suite_golden.py).
+    Every case whose agents do not swap places exactly must end as in the reference -- outcome, step count, time to
+    goal, final flags -- and the aggregate rates of all 500 must agree within a few episodes (the swap cases are
+    symmetric head-on encounters decided by the last bit of atan2, where ROCm's libm and glibc differ: DESIGN.md section 5)."""
+    nat, core, orc = _mods()
+    ref = gu.load_suite(name)
+    cases = gu.suite_cases(name)
+    E, N = cases.shape[:2]
+    g = core.BatchedSim(core.make_params(E, N, ragged=int(name == "ragged4")))
+    g.set_plugins(nat.POL_RVO)
+    g.reset(cases)
+    if name == "ragged4":
+        assert np.array_equal((g.state["flags"].cpu().numpy() >> 16 & 1).sum(1), 4 - ref["num_agents"])
+
+    def step():
+        g.step()
+        return g.game_over.cpu().numpy(), {k: g.state[k].cpu().numpy() for k in ("t", "slt", "ep_reward", "pos_x", "pos_y")}
+
+    got = gu.run_suite(g, cases, lambda: g.state["flags"].cpu().numpy().astype(np.uint32), step)
+    swap = _swap_cases(cases)
+    same = (got["outcome"] == ref["outcome"]) & (got["steps"] == ref["steps"]) & (got["flags"] == ref["flags"]).all(1) & \
+           (np.abs(got["time_to_goal"] - ref["time_to_goal"]).max(1) < 1e-6) & \
+           (np.abs(got["pos"] - ref["pos"]).max((1, 2)) < 1e-3)
+    assert same[~swap].all(), "cases %s differ from the reference without an exact swap in them" % np.nonzero(~same & ~swap)[0][:20]
+    assert same.mean() > 0.9
+    for oc in range(3):
+        assert abs(int((got["outcome"] == oc).sum()) - int((ref["outcome"] == oc).sum())) <= 12, (oc, got["outcome"], ref["outcome"])
+    assert abs(got["steps"].mean() - ref["steps"].mean()) < 0.05 * ref["steps"].mean()
+
+
+# ---------------------------------------------------------------- round 3: ragged batches (per-env agent counts)
+@pytest.mark.parametrize("N,E,K", [(4, 600, 3), (10, 512, 9), (10, 512, 4), (20, 60, 19), (6, 77, 8)])
+def test_ragged_batches_vs_oracle_reinjected(N, E, K):
+    """envs with fewer agents than num_agents (CA_ABSENT slots: a case row with radius 0): neighbours, collisions,
+    sensing, num_other_agents, zero padding, game over and episode statistics follow the env's OWN agent list like the
+    reference's loops over len(self.agents); re-injected from the oracle every step, with auto-reset from a ragged table."""
+    nat, core, orc = _mods()
+    rng = np.random.default_rng(N * 100 + E)
+    table = gu.fixtures(N).copy()
+    n_e = rng.integers(2, N + 1, size=table.shape[0])
+    for c in range(table.shape[0]):
+        table[c, n_e[c]:] = 0.0
+    o, g = _pair(E, N, K=K, ragged=1)
+    o.s["policy"][:] = orc.POL_RVO
+    g.set_plugins(nat.POL_RVO)
+    g.set_fixture_table(table)
+    cases = table[np.arange(E) % table.shape[0]]
+    o.reset(cases)
+    g.reset(cases)
+    _compare_reset(o, g)
+    o.rollout(table, 70)
+    for t in range(90):
+        _upload(o, g)
+        o.rollout(table, 1)
+        g.step()
+        _compare(o, g, what="ragged N=%d step %d" % (N, t))
+        np.testing.assert_allclose(g.state["env_stats"].cpu().numpy(), o.s["env_stats"], rtol=0, atol=1e-6)
+    assert o.s["env_stats"][:, 0].sum() > E // 4
+    absent = (o.view("flags") >> 16 & 1).astype(bool)
+    assert absent.any() and not g.obs.cpu().numpy()[absent].any() and g.done.cpu().numpy()[absent].all()
