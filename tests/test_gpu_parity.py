@@ -92,7 +92,7 @@ def _compare(o, g, tol=TOL, what=""):
 
 def test_library_loads_on_gpu():
     nat, core, orc = _mods()
-    assert nat.lib().cagpu_version() == 4
+    assert nat.lib().cagpu_version() == nat.ABI_VERSION
     assert torch.cuda.is_available()
 
 
@@ -789,7 +789,10 @@ def test_auto_reset_without_precomputed_observations():
             assert torch.equal(sims[0].obs, sims[1].obs), t
     assert float(sims[0].episode_stats()[0]) > 100        # plenty of auto-resets happened
     for n in F64 + ("flags", "step_num", "episode_step", "reset_count", "env_stats"):
-        assert torch.equal(sims[0].state[n], sims[1].state[n]), n
+        x, y = sims[0].state[n], sims[1].state[n]
+        if n == "flags":   # (PLAN_VALID is bookkeeping: without reset observations the unpipelined kernel runs)
+            x, y = x & ~nat.PLAN_VALID, y & ~nat.PLAN_VALID
+        assert torch.equal(x, y), n
     assert torch.equal(sims[0].rewards, sims[1].rewards) and torch.equal(sims[0].done, sims[1].done)
 
 
