@@ -292,6 +292,12 @@ class Executor(object):
             return [I(0) >= I(1)]
         if op == "Equal":
             return [I(0) == I(1)]
+        if op == "LogicalAnd":
+            return [np.logical_and(I(0), I(1))]
+        if op == "Maximum":
+            return [np.maximum(I(0), I(1))]
+        if op == "Minimum":
+            return [np.minimum(I(0), I(1))]
         if op == "Select":
             c, x, y = I(0), I(1), I(2)
             if c.ndim == 1 and x.ndim > 1:      # a vector condition selects ROWS
