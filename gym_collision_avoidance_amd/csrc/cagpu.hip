@@ -2067,6 +2067,13 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
   return launch_any(k, stream);
 }
 
+#ifdef CAGPU_PIPETIME
+int cagpu_debug_pipetime(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pipe::g_pipetime), sizeof(unsigned long long) * 1024 * 32);
+  return 0;
+}
+#endif
 #ifdef CAGPU_WGTIME
 int cagpu_debug_wgtime(unsigned long long* out) {
   (void)hipDeviceSynchronize();

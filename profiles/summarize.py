@@ -32,7 +32,7 @@ def counters(d):
     agg = collections.defaultdict(list)
     meta = {}
     for r in csv.DictReader(open(f[0])):
-        if "ca_kernel" in r["Kernel_Name"] or "ga3c" in r["Kernel_Name"] or "scan_kernel" in r["Kernel_Name"]:
+        if "ca_kernel" in r["Kernel_Name"] or "ca_pipe_kernel" in r["Kernel_Name"] or "ga3c" in r["Kernel_Name"] or "scan_kernel" in r["Kernel_Name"]:
             short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",

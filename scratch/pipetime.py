@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""scratch/pipetime.py -- stage-boundary wall-clock stamps of the pipelined step kernel (build variant pipetime_fast):
+where a workgroup's step goes, how the slowest workgroups of a launch differ from the mean.
+    python gym_collision_avoidance_amd/build_native.py pipetime_fast
+    CAGPU_LIB=gym_collision_avoidance_amd/libcagpu_pipetime_fast.so python scratch/pipetime.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gym_collision_avoidance_amd import _native as nat, core  # noqa: E402
+
+E = int(os.environ.get("E", "4096"))
+table = np.load(os.path.join(os.path.dirname(nat.HERE), "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n10"]
+sim = core.BatchedSim(core.make_params(E, 10))
+sim.set_plugins(nat.POL_RVO)
+sim.set_fixture_table(table)
+sim.reset_from_table()
+lib = nat.lib()
+for _ in range(400):
+    sim.step()
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (1024 * 32))()
+rows = []
+for rep in range(20):
+    for _ in range(37):
+        sim.step()
+    lib.cagpu_debug_pipetime(buf)
+    rows.append(np.frombuffer(buf, dtype=np.uint64).reshape(1024, 32)[:E // 4].astype(np.int64).copy())
+print(lib.cagpu_last_kernel().decode())
+tick = 0.01
+W0 = ["start", "loaded", "B_A", "moved(pre-move pt)", "published", "B_P", "B_1", "A3 done", "B_2", "A4 done", "B_3", "B_4", "stored"]
+W4 = ["B_P", "P2 done", "B_1", "P2b done", "B_2", "scan done", "B_3", "lp3 done", "after B_4", "post done"]
+dur, span, seg0, seg4, slow0, slow4, n3s, lives = [], [], [], [], [], [], [], []
+for a in rows:
+    t0 = a[:, 0]
+    end = np.maximum(a[:, 12], a[:, 25])
+    d = (end - t0) * tick
+    dur.append(d)
+    span.append((end.max() - t0.min()) * tick)
+    w0 = a[:, 0:13].copy()
+    w0[:, 11] = np.where(a[:, 13] & 0xFF, w0[:, 11], w0[:, 10])     # (no B_4 stamp path is still stamped: same time)
+    s0 = np.diff(w0, axis=1) * tick
+    w4 = a[:, 16:26].copy()
+    noq = (a[:, 13] & 0xFF) == 0
+    w4[noq, 7] = w4[noq, 6]
+    s4 = np.diff(w4, axis=1) * tick
+    seg0.append(s0); seg4.append(s4)
+    k = np.argsort(end)[-10:]
+    slow0.append(s0[k]); slow4.append(s4[k])
+    n3s.append(a[:, 13] & 0xFF); lives.append((a[:, 13] >> 8) & 0xFF)
+dur = np.concatenate(dur); seg0 = np.concatenate(seg0); seg4 = np.concatenate(seg4)
+slow0 = np.concatenate(slow0); slow4 = np.concatenate(slow4); n3s = np.concatenate(n3s); lives = np.concatenate(lives)
+print("workgroup duration (start -> last store): mean %.2f p50 %.2f p90 %.2f p99 %.2f p99.9 %.2f max %.2f us; first start -> last end per launch: mean %.2f" % (
+    dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), np.percentile(dur, 99.9), dur.max(), np.mean(span)))
+print("wave 0 segments (mean all | mean of the 10 last-finishing workgroups per launch):")
+for i in range(12):
+    print("   %-22s -> %-22s %6.2f | %6.2f" % (W0[i], W0[i + 1], seg0[:, i].mean(), slow0[:, i].mean()))
+print("wave 4 segments:")
+for i in range(9):
+    print("   %-22s -> %-22s %6.2f | %6.2f" % (W4[i], W4[i + 1], seg4[:, i].mean(), slow4[:, i].mean()))
+for lo, hi in ((0, 0), (1, 1), (2, 2), (3, 4), (5, 99)):
+    m = (n3s >= lo) & (n3s <= hi)
+    if m.any():
+        print("   lp3 queue %d..%d: %5.1f %% of the workgroups, duration mean %.2f p90 %.2f" % (lo, hi, 100 * m.mean(), dur[m].mean(), np.percentile(dur[m], 90)))
+for lo, hi in ((0, 16), (17, 24), (25, 28), (29, 40)):
+    m = (lives >= lo) & (lives <= hi)
+    if m.any():
+        print("   planned agents %d..%d: %5.1f %%, duration mean %.2f p90 %.2f" % (lo, hi, 100 * m.mean(), dur[m].mean(), np.percentile(dur[m], 90)))
