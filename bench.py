@@ -34,12 +34,13 @@ GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
 def measured_traffic_bytes(envs, agents):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, profiles/), if they were
     taken at this geometry; bench.py itself does not run the profiler."""
-    f = os.path.join(REPO, "profiles", "r02_traffic.json")
-    if os.path.exists(f):
-        d = json.load(open(f))
-        if d.get("envs") == envs and d.get("agents") == agents:
-            return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0
-    return None
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        f = os.path.join(REPO, "profiles", name)
+        if os.path.exists(f):
+            d = json.load(open(f))
+            if d.get("envs") == envs and d.get("agents") == agents:
+                return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0, "profiles/" + name
+    return None, None
 
 
 def algorithmic_bytes_per_agent_step(K):
@@ -76,7 +77,7 @@ def cpu_baseline(n_agents, K, budget_s=8.0):
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     s1, d1 = _port_leg((n_agents, K, budget_s, 0))
-    allv, procs = None, min(cores, 64)
+    allv, procs = None, cores          # one process per LOGICAL core of this host
     try:
         with mp.get_context("spawn").Pool(procs) as pool:
             res = pool.map(_port_leg, [(n_agents, K, budget_s, r) for r in range(procs)])
@@ -91,10 +92,42 @@ def cpu_baseline(n_agents, K, budget_s=8.0):
     ref = os.path.join(REPO, "profiles", "r02_reference_cpu.json")
     if os.path.exists(ref):
         r = json.load(open(ref))
-        out["reference_python"] = {"kind": "reference", "where": "build container (the reference does not travel to the GPU box)",
+        out["reference_python"] = {"kind": "reference", "measured_where": "build container (the reference does not travel to the GPU box)",
                                    "host": r["host"], "one_process": r["one_process"]["agent_steps_per_s"],
                                    "all_cores": r["all_cores"]["agent_steps_per_s"], "cores": r["all_cores"]["cores"],
                                    "script": "oracle/time_reference.py"}
+    return out
+
+
+def env_api_rates(E, N, steps, torch, dev):
+    """What a drop-in user calls: CollisionAvoidanceEnv(num_envs=E).step(None) through the gym-level API of
+    gym_collision_avoidance_amd.envs (fresh output tensors per step by default; zero_copy=True hands out the persistent
+    buffers).  Host wall clock per step, device idle at start and end."""
+    os.environ.setdefault("GYM_CONFIG_CLASS", "EvaluateConfig")
+    out = {}
+    try:
+        from gym_collision_avoidance_amd.envs import Config
+        from gym_collision_avoidance_amd.envs.collision_avoidance_env import CollisionAvoidanceEnv
+        Config.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
+        Config.MAX_NUM_OTHER_AGENTS_OBSERVED = N - 1
+        for zc in (False, True):
+            env = CollisionAvoidanceEnv(num_envs=E, device=str(dev), zero_copy=zc)
+            env.set_fixture_suite(N)
+            env.reset()
+            for _ in range(100):
+                env.step(None)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                env.step(None)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            out["zero_copy" if zc else "default"] = {"value": E * N * steps / dt, "unit": "agent-steps/s",
+                                                     "us_per_step": dt / steps * 1e6}
+        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; default = fresh obs / reward / "
+                       "game_over tensors per step, zero_copy = the persistent device buffers" % (E, steps))
+    except Exception as e:  # noqa: BLE001 -- an extra must never take the bench line down
+        out["error"] = repr(e)
     return out
 
 
@@ -270,6 +303,7 @@ def main():
     if world > 1:
         dist.barrier()
     gpu_ms = ev0.elapsed_time(ev1)
+    gpu_ms_local = gpu_ms
     if world > 1:
         tmax = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -277,6 +311,24 @@ def main():
     stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective (8 counters), outside the clock
     torch.cuda.synchronize(dev)
     kernel_name = nat.lib().cagpu_last_kernel().decode()
+    # ---- multi-GPU evidence the driver can read from the JSON line: ranks seen, per-rank device time of the SAME K
+    # steps, and the latency of the one collective (the 8-counter all-reduce), measured outside the step clock
+    per_rank_ms, allreduce_us = [gpu_ms_local / a.steps], None
+    if world > 1:
+        mine = torch.tensor([gpu_ms_local / a.steps], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x.item()) for x in every]
+        probe = sim.episode_stats()
+        for _ in range(5):
+            reduce_episode_stats(probe, world)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t_c = time.perf_counter()
+        for _ in range(50):
+            reduce_episode_stats(probe, world)
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - t_c) / 50 * 1e6
 
     if rank == 0:
         agent_steps = float(world) * E * N * a.steps
@@ -297,12 +349,16 @@ def main():
                        "envs_per_gpu": E, "agents": N, "launch_mode": a.mode, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic_bytes(E, N) if a.mode == "step" else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02_rocprof_summary.md)",
+                         "traffic": measured_traffic_bytes(E, N)[0] if a.mode == "step" else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command, committed as %s; "
+                                         "not re-measured in this run)" % measured_traffic_bytes(E, N)[1],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": kernel_name, "avg_launch_us": kern_s * 1e6,
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
+            "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+            "per_rank_event_ms_per_step": per_rank_ms,
+            "stats_allreduce_us": allreduce_us,   # the ONLY collective (RCCL all-reduce of 8 float64 counters), off the step path
         }
         if a.workload != "rvo10":
             extra_workload(out, a, sim, core, E, N, K, dev, torch)
@@ -364,6 +420,8 @@ def main():
                                           "two branches of one HIP graph (the ramp-up and the tail of one chain's launch "
                                           "overlap with the body of the other's); not the headline: per-launch durations "
                                           "overlap, so the roofline above is quoted for the single-chain launch" % (E // 2, nrep)}
+        if world == 1 and a.mode == "step" and a.workload == "rvo10" and not a.no_extras:
+            out["env_api"] = env_api_rates(E, N, min(a.steps, 1000), torch, dev)
         if world == 1 and not a.no_cpu_baseline and a.workload == "rvo10":
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))

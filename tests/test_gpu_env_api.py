@@ -343,3 +343,77 @@ def test_env_rollout_matches_repeated_steps():
     env.reset()
     with pytest.raises(ValueError):
         env.rollout(5)
+
+
+# ---------------------------------------------------------------- round 3: ragged batches through the env API
+def test_default_config_batched_reset_draws_per_env_agent_counts():
+    """The reference's default Config (TEST_CASE_FN = get_testcase_random: 2 .. MAX agents and a policy lottery per
+    episode, config.py:50-63, test_cases.py:212-253) at num_envs > 1: every env draws its own scenario, short envs leave
+    their last slots empty, and the batch steps like the per-env reference loops -- checked against the CPU oracle,
+    re-injected every step, with the learners driven by external actions."""
+    import os
+    os.environ.pop("GYM_CONFIG_PATH", None)
+    os.environ.pop("GYM_CONFIG_CLASS", None)
+    import sys
+    for m in [m for m in sys.modules if m.startswith("gym_collision_avoidance_amd.envs")]:
+        del sys.modules[m]
+    from gym_collision_avoidance_amd.envs import Config
+    from gym_collision_avoidance_amd.envs.collision_avoidance_env import CollisionAvoidanceEnv
+    from gym_collision_avoidance_amd import _native as nat
+    from oracle import ca_oracle as orc
+    from tests.test_gpu_parity import _upload, _compare
+    E = 96
+    np.random.seed(11)
+    env = CollisionAvoidanceEnv(num_envs=E)
+    obs, _ = env.reset()
+    sim = env._sim
+    N, K = sim.N, sim.K
+    assert N == Config.MAX_NUM_AGENTS_IN_ENVIRONMENT == 4 and obs.shape == (E, N, 6 + 7 * K)
+    fl = sim.state["flags"].cpu().numpy().astype(np.uint32)
+    absent = (fl >> 16 & 1).astype(bool)
+    n_e = N - absent.sum(1)
+    assert set(np.unique(n_e)) == {2, 3, 4} and sim.p.ragged == 1
+    o_np = obs.cpu().numpy()
+    assert not o_np[absent].any()
+    here = ~absent
+    assert np.array_equal(o_np[..., 1][here], np.minimum(np.broadcast_to((n_e - 1)[:, None], (E, N)), K)[here])
+    # the same batch in the oracle (state copied from the device: identical reset state by construction of _upload's inverse)
+    po = orc.default_params(E, N, max_obs=K, dt=Config.DT, max_time_ratio=Config.MAX_TIME_RATIO, ragged=1,
+                            game_over_mode=orc.OVER_LEARNING_DONE)
+    o = orc.Oracle(po)
+    o.s["policy"][:] = ((fl >> 8) & 0xF).reshape(-1)
+    o.s["dynamics"][:] = ((fl >> 12) & 0xF).reshape(-1)
+    from tests.test_gpu_parity import _download
+    _download(sim, o)
+    o.s["flags"][:] = (fl.reshape(-1) & 0xFF) | (fl.reshape(-1) & orc.ABSENT)
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        ext = rng.uniform(0, 1, (E, N, 2))
+        ext[..., 0] = rng.integers(0, 11, (E, N))        # learning_ga3c: a discrete action index
+        o.step(ext)
+        env.step(ext)
+        _compare(o, sim, what="default-config batch, step %d" % t)
+        _upload(o, sim)
+    envtools.default()
+
+
+def test_ragged_fixture_table_through_the_env_api():
+    """set_fixture_suite(table=<ragged table>): 2-, 3- and 4-agent cases in 4-slot envs with on-device auto-reset -- the
+    reference-recorded suite rows (tests/golden/suite_ragged4.npz) through CollisionAvoidanceEnv + run_suite"""
+    Config, tc, Env = envtools.fresh("Swap4")
+    ref = gu.load_suite("ragged4")
+    table = gu.suite_cases("ragged4")
+    env = Env(num_envs=500)
+    env.set_fixture_suite(4, policies="RVO", table=table, auto_reset=False)
+    obs, _ = env.reset()
+    assert env._sim.p.ragged == 1 and len(env.agents) == 2
+    for _ in range(int(ref["steps"].max()) + 5):
+        obs, rew, over, _, info = env.step(None)
+    assert bool(over.all())
+    fl = env._sim.state["flags"].cpu().numpy().astype(np.uint32)
+    here = (fl >> 16 & 1) == 0
+    coll = (((fl & 4) != 0) & here).any(1)
+    goal = (((fl & 1) != 0) | ~here).all(1)
+    outcome = np.where(coll, 0, np.where(goal, 1, 2))
+    assert (outcome == ref["outcome"]).mean() > 0.97
+    envtools.default()
