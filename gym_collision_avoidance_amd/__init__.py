@@ -20,16 +20,24 @@ def register_with_gym():
     for name in ("gym", "gymnasium"):
         try:
             mod = __import__(name + ".envs.registration", fromlist=["register"])
-        except ImportError:
-            continue
+        except Exception:  # noqa: BLE001 -- absent, or an installed gym that fails to import (numpy 2 vs old gym): never
+            continue       # a reason for `import gym_collision_avoidance_amd` to fail
         registry = getattr(mod, "registry", None)
         known = False
         try:  # gym < 0.26: EnvRegistry with .env_specs; newer gym / gymnasium: a plain dict
             known = ENV_ID in (registry.env_specs if hasattr(registry, "env_specs") else registry)
         except TypeError:
             known = False
-        if not known:
-            mod.register(id=ENV_ID, entry_point=ENTRY_POINT)
+        try:
+            if not known:
+                # (the env derives from the package's own minimal Env / spaces: gym >= 0.26 and gymnasium check the class
+                # and the spaces in make(), so their checker is switched off for this id)
+                try:
+                    mod.register(id=ENV_ID, entry_point=ENTRY_POINT, disable_env_checker=True)
+                except TypeError:
+                    mod.register(id=ENV_ID, entry_point=ENTRY_POINT)
+        except Exception:  # noqa: BLE001
+            continue
         done.append(name)
     return done
 

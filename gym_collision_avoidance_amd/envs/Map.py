@@ -9,22 +9,33 @@ import numpy as np
 
 
 def load_map_image(map_filename, dims):
-    """Map.py:17-22 without scipy.misc.imresize (removed from SciPy): uint8 grey image, nearest resize, invert."""
+    """Map.py:17-22 without scipy.misc.imresize (removed from SciPy): the image as 8-bit grey levels, imresize's
+    bytescale (min .. max stretched to 0 .. 255 when the image has to be resized), nearest-neighbour resize, invert:
+    dark pixels are obstacles."""
+    img = None
     try:
-        import imageio
-        img = np.asarray(imageio.imread(map_filename))
+        from PIL import Image
+        img = np.asarray(Image.open(map_filename).convert("L"))   # palette / RGB(A) / 1-bit -> grey levels 0 .. 255
     except ImportError:
-        from PIL import Image
-        img = np.asarray(Image.open(map_filename))
-    if img.ndim == 3:  # colour / alpha: the reference's maps are single-channel; take the first channel
-        img = img[..., 0]
-    if img.dtype == bool:
-        img = img.astype(np.uint8) * 255
-    img = img.astype(np.uint8)
+        Image = None
+        try:
+            import imageio
+            img = np.asarray(imageio.imread(map_filename))
+        except ImportError:
+            raise ImportError("reading a map image needs Pillow or imageio (neither is installed); pass the occupancy grid "
+                              "itself with Map(..., static_map=<bool array>) / env.set_static_map(<bool array>)")
+        if img.ndim == 3:
+            img = img[..., :3].mean(axis=-1)
+        if img.dtype == bool:
+            img = img.astype(np.uint8) * 255
+    img = np.asarray(img)
     if img.shape != tuple(dims):
-        from PIL import Image
-        img = np.asarray(Image.fromarray(img).resize((dims[1], dims[0]), Image.NEAREST))
-    return np.invert(img).astype(bool)
+        if Image is None:
+            raise ImportError("resizing a %s map image to %s needs Pillow" % (img.shape, tuple(dims)))
+        lo, hi = float(img.min()), float(img.max())            # scipy.misc.bytescale, as imresize applied it
+        scaled = np.zeros(img.shape, np.uint8) if hi == lo else np.clip((img - lo) * (255.0 / (hi - lo)) + 0.5, 0, 255).astype(np.uint8)
+        img = np.asarray(Image.fromarray(scaled).resize((dims[1], dims[0]), Image.NEAREST))
+    return np.invert(img.astype(np.uint8)).astype(bool)
 
 
 class Map(object):

@@ -245,7 +245,7 @@ class CollisionAvoidanceEnv(Env):
         self._host_policies = []
         for i, a in enumerate(agents):
             p = a.policy
-            if type(p) in _BUILTIN_POLICIES:
+            if type(p) in _BUILTIN_POLICIES and not getattr(p, "needs_host", False):
                 pol.append(p.kernel_id)
             else:  # user plugin: queried on the host, handed to the kernel as a raw command
                 pol.append(nat.POL_EXTERNAL)
@@ -325,8 +325,12 @@ class CollisionAvoidanceEnv(Env):
             heads = None
             if f["heading_seed"]:  # training mode: random initial headings (test_cases.py:558-559), drawn on the device
                 import torch
+                # a fresh stream per reset() call and per shard (seed, call count, global id of this shard's env 0):
+                # successive resets and the shards of a multi-GPU batch draw different headings
+                self._heading_resets = getattr(self, "_heading_resets", 0) + 1
                 gen = torch.Generator(device=sim.device)
-                gen.manual_seed(f["heading_seed"])
+                gen.manual_seed((int(f["heading_seed"]) * 0x9E3779B1 + self._heading_resets * 0x85EBCA77 +
+                                 int(f["env_id_offset"]) * 0xC2B2AE3D) & 0x7FFFFFFFFFFFFFFF)
                 heads = (torch.rand((E, N), generator=gen, device=sim.device, dtype=torch.float64) * 2.0 - 1.0) * np.pi
             sim.reset(f["table"][idx], headings=heads)
             groups = [agents0]

@@ -417,3 +417,54 @@ def test_ragged_fixture_table_through_the_env_api():
     outcome = np.where(coll, 0, np.where(goal, 1, 2))
     assert (outcome == ref["outcome"]).mean() > 0.97
     envtools.default()
+
+
+def test_rvo_policy_is_host_callable_and_equals_the_kernels_action():
+    """InternalPolicy.find_next_action(obs, agents, i) (InternalPolicy.py:12-23) on an RVOPolicy object: the host path
+    (cagpu_orca + RVOPolicy.py:96-122 in numpy) returns the action the step kernel then takes, bit for bit as float32;
+    with heading_noise switched on the agent is queried on the host with the reference's own np.random draw"""
+    Config, tc, Env = envtools.fresh("Swap4")
+    env = Env()
+    agents = tc.cadrl_test_case_to_agents(tc.preset_testCases(4, full_test_suite=True)[7], policies="RVO")
+    env.set_agents(agents)
+    obs, _ = env.reset()
+    for t in range(25):
+        want = [np.asarray(a.policy.find_next_action(obs, agents, i), dtype=np.float32) for i, a in enumerate(agents)]
+        done = [bool(a.is_done) for a in agents]
+        obs, rew, over, _, info = env.step({})
+        for i, a in enumerate(agents):
+            if not done[i]:
+                assert np.array_equal(np.asarray(a.past_actions[0], dtype=np.float32), want[i]), (t, i)
+    # heading noise: np.random.normal(0, 0.5) on top of the deterministic turn, like RVOPolicy.py:118-119
+    env2 = Env()
+    agents2 = tc.cadrl_test_case_to_agents(tc.preset_testCases(4, full_test_suite=True)[7], policies="RVO")
+    agents2[1].policy.heading_noise = True
+    env2.set_agents(agents2)
+    obs2, _ = env2.reset()
+    assert env2._host_policies == [1]
+    np.random.seed(3)
+    noise = np.random.normal(0, 0.5)
+    np.random.seed(3)
+    clean = agents[1].policy.__class__().find_next_action(obs2, agents2, 1)
+    np.random.seed(3)
+    env2.step({})
+    assert abs(float(agents2[1].past_actions[0][1]) - np.float32(clean[1] + noise)) < 1e-6
+    envtools.default()
+
+
+def test_training_mode_reset_headings_differ_between_resets_and_shards():
+    Config, tc, Env = envtools.fresh("Train5")
+    heads = []
+    for off in (0, 0, 64):
+        env = Env(num_envs=64)
+        env.set_fixture_suite(5, policies="RVO", table=np.tile(tc.fixture_table(5)[:8], (1, 1, 1)), env_id_offset=off,
+                              case_stride=128, random_headings=True, heading_seed=9)
+        env.reset()
+        h1 = env._sim.state["heading"].cpu().numpy().copy()
+        env.reset()
+        h2 = env._sim.state["heading"].cpu().numpy().copy()
+        assert not np.array_equal(h1, h2)            # a second reset() draws new headings
+        assert h1.min() >= -np.pi and h1.max() < np.pi
+        heads.append(h1)
+    assert np.array_equal(heads[0], heads[1]) and not np.array_equal(heads[0], heads[2])   # reproducible; shards differ
+    envtools.default()
