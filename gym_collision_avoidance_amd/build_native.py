@@ -34,12 +34,14 @@ def build(force=False, verbose=False, variant=None):
     out = OUT if variant is None else os.path.join(HERE, "libcagpu_%s.so" % variant)
     # "ablate_fast" / "knobs_fast": the same with only the N = 10 unstaged instantiations compiled (quick iterations)
     # "exp<mask>_fast": compile-time experiment switches, -DCAGPU_EXP=<mask> (see EXP() in cagpu.hip)
-    # and "dKEY=VAL" -> -DCAGPU_KEY=VAL
+    # and "dKEY=VAL" -> -DCAGPU_KEY=VAL; tokens are separated by "_", or by "," when a KEY itself contains "_"
+    # (e.g. "dPIPE_WT=0,fast" -> -DCAGPU_PIPE_WT=0 -DCAGPU_FAST)
     # "fFLAG" tokens pass an -mllvm option through (compiler experiments), e.g. famdgpu-enable-max-ilp-scheduling-strategy
     extra = [] if variant is None else [("-DCAGPU_EXP=%s" % v[3:]) if v.startswith("exp") else
                                         ("-mllvm=-%s" % v[1:]) if (v.startswith("f") and v not in ("fast",)) else
                                         ("-DCAGPU_%s" % v[1:]) if (v.startswith("d") and "=" in v) else
-                                        "-DCAGPU_%s" % v.upper() for v in variant.split("_")]
+                                        "-DCAGPU_%s" % v.upper() for v in
+                                        (variant.split(",") if "," in variant or "=" in variant else variant.split("_"))]
     extra = [y for x in extra for y in (["-mllvm", x[len("-mllvm="):]] if x.startswith("-mllvm=") else [x])]
     cmd = [hipcc] + FLAGS + extra + [SRC, "-o", out]
     if variant is not None:

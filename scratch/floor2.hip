@@ -51,6 +51,10 @@ int main() {
   printf("empty 1024 x 512,  1 KB LDS   %.2f us\n", run(k_empty<512>, buf, 0, grid, 512, 1024, 3000));
   printf("empty  512 x 512, 34 KB LDS   %.2f us\n", run(k_empty<512>, buf, 0, 512, 512, 34 * 1024, 3000));
   printf("empty 2048 x 256, 17 KB LDS   %.2f us\n", run(k_empty<256>, buf, 0, 2048, 256, 17 * 1024, 3000));
+  for (int kb : {1, 8, 16, 20, 24, 28, 31, 32, 33, 36, 40})
+    printf("empty 1024 x 512, %2d KB LDS   %.2f us\n", kb, run(k_empty<512>, buf, 0, grid, 512, kb * 1024, 3000));
+  for (int g : {256, 512, 768, 1024, 1280, 2048})
+    printf("empty %4d x 512, 33 KB LDS   %.2f us\n", g, run(k_empty<512>, buf, 0, g, 512, 33 * 1024, 3000));
   for (int mode = 0; mode < 3; ++mode)
     printf("1024 x 512 storing 11.3 MB, mode %d (0 plain, 1 nontemporal, 2 system scope)   %.2f us\n", mode,
            run(k_store<512>, buf, (mode << 24) | per_wg, grid, 512, 34 * 1024, 3000));
