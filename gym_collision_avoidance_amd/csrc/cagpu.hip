@@ -1799,14 +1799,18 @@ int launch_main(const KArgs& k, hipStream_t st) {
 }
 
 // The software-pipelined kernel (cagpu_pipe.inc): the caller handed over CaState.next_action, the agent count has an
-// instantiation, the sensor sorts closest_first, an attached fixture table comes with its reset observations, and every
-// workgroup of the launch is resident at once (4 per CU).
+// instantiation, the sensor sorts closest_first, an attached fixture table comes with its reset observations, and the
+// grid suits its 4-env tiles.
 bool pipe_eligible(const KArgs& k) {
   if (!k.s.next_action || k.p.num_agents != 10 || k.stage_obs) return false;
   if (k.mode != MODE_STEP && k.mode != pipe::MODE_PLAN) return false;
   if (k.p.sort_mode != CA_SORT_CLOSEST_FIRST) return false;
   if (k.table && !k.reset_obs) return false;
-  return (static_cast<long>(k.p.num_envs) + 3) / 4 <= 4L * device_cus();
+  // grid: one round of resident workgroups (4 per CU), or at least two -- in between (1.5 rounds at 6144 envs) ca_kernel's
+  // 6-env tiles fit the device better: 21.3 vs 22.9 us per step; from 8192 envs on this kernel is ahead again (28.9 vs 33.0
+  // us; 32768 envs: 85.1 vs 87.8, fused rollout 65.7 vs 87.5 us per step; profiles/r03_kernel_geometry.md)
+  const long wgs = (static_cast<long>(k.p.num_envs) + 3) / 4, cap = 4L * device_cus();
+  return wgs <= cap || wgs >= 2 * cap;
 }
 
 template <int NC, int TE, bool MULTI>
@@ -1838,7 +1842,7 @@ int launch_any(const KArgs& k0, void* stream) {
 #ifndef CAGPU_NOPIPE
   if (pipe_eligible(k)) return launch_pipe(k, st);
 #endif
-  if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents == 10, closest_first sorting and at most 4 x CUs tiles%s");
+  if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents == 10, closest_first sorting and a grid of at most 4 x CUs or at least 8 x CUs tiles%s");
   k.tile_envs = ROW / N;
   k.col_stride = (N > 32) ? (CAGPU_CSPAD ? (N | 1) : N) : CS_ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
   // N = 10: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all co-resident, evenly
