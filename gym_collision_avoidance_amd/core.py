@@ -137,7 +137,7 @@ class BatchedSim(object):
 
     def ga3c_rows(self):
         """number of agents the last ga3c() call evaluated (device -> host read: synchronises)"""
-        return int(self._net_tensors["rows_scratch"][-1].item())
+        return int(self._net_tensors["rows_scratch"][self.E * self.N].item())
 
     def load_ga3c(self, weights=None, keep_logits=False):
         """Upload the GA3C-CADRL network (GA3CCADRLPolicy.initialize_network, GA3CCADRLPolicy.py:23-47).  `weights`:
@@ -159,7 +159,7 @@ class BatchedSim(object):
                 raise ValueError("GA3C-CADRL weight %s has shape %s, expected %s" % (f, a.shape, shapes[f]))
             ts[f] = torch.from_numpy(a).to(self.device)
         # scratch of cagpu_ga3c: the packed list of the agents that need an action this step (+ their count)
-        ts["rows_scratch"] = torch.zeros((self.E * self.N + 1,), dtype=torch.int32, device=self.device)
+        ts["rows_scratch"] = torch.zeros((self.E * self.N + 3,), dtype=torch.int32, device=self.device)
         self._net_tensors = ts
         self._net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch",)})
         self.ga3c_logits = torch.zeros((self.E, self.N, 11), dtype=torch.float32, device=self.device) \

@@ -1992,8 +1992,8 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   k.rows = net->rows_scratch;
   if (k.rows) {
     if (k.B >= (1L << 31)) return fail(CA_EUNSUPPORTED, "cagpu_ga3c: more than 2^31 agents with rows_scratch%s");
-    hipLaunchKernelGGL(ga3c::compact_kernel, dim3(1), dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B,
-                       net->rows_scratch);
+    hipLaunchKernelGGL(ga3c::compact_kernel, dim3(static_cast<unsigned>((k.B + 4 * ga3c::CP_NT - 1) / (4 * ga3c::CP_NT))),
+                       dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch);
   }
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
   static thread_local bool lds_raised[16] = {false};
