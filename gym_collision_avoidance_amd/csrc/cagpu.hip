@@ -1802,13 +1802,19 @@ int launch_main(const KArgs& k, hipStream_t st) {
 // instantiation, the sensor sorts closest_first, an attached fixture table comes with its reset observations, and the
 // grid suits its 4-env tiles.
 bool pipe_eligible(const KArgs& k) {
-  if (!k.s.next_action || k.p.num_agents != 10 || k.stage_obs) return false;
+  const int n = k.p.num_agents;
+  if (!k.s.next_action || k.stage_obs) return false;
+#ifdef CAGPU_FAST
+  if (n != 10) return false;
+#endif
+  if (!(n == 10 || n == 8 || n == 6 || n == 5 || n == 4 || n == 3 || n == 2)) return false;  // (the instantiations)
   if (k.mode != MODE_STEP && k.mode != pipe::MODE_PLAN) return false;
   if (k.p.sort_mode != CA_SORT_CLOSEST_FIRST) return false;
   if (k.table && !k.reset_obs) return false;
   // grid: one round of resident workgroups (4 per CU), or at least two -- in between (1.5 rounds at 6144 envs) ca_kernel's
   // 6-env tiles fit the device better: 21.3 vs 22.9 us per step; from 8192 envs on this kernel is ahead again (28.9 vs 33.0
   // us; 32768 envs: 85.1 vs 87.8, fused rollout 65.7 vs 87.5 us per step; profiles/r03_kernel_geometry.md)
+  if (n != 10) return true;
   const long wgs = (static_cast<long>(k.p.num_envs) + 3) / 4, cap = 4L * device_cus();
   return wgs <= cap || wgs >= 2 * cap;
 }
@@ -1816,7 +1822,8 @@ bool pipe_eligible(const KArgs& k) {
 template <int NC, int TE, bool MULTI>
 int launch_pipe2(const KArgs& k, hipStream_t st) {
   using G = pipe::Geo<NC, TE>;
-  static_assert(G::LDS <= 40 * 1024, "four workgroups per CU");
+  static_assert(G::LDS <= 48 * 1024 && (NC != 10 || G::LDS <= 40 * 1024), "three (metric geometry: four) workgroups per CU");
+  static_assert(TE <= 32 && NC * TE <= 64 && NC >= 2 && NC <= 10, "one agent wave per half; lp3_wave8 holds at most 9 lines");
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + TE - 1) / TE);
   std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d", NC, TE,
                 MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode);
@@ -1826,9 +1833,25 @@ int launch_pipe2(const KArgs& k, hipStream_t st) {
   return CA_OK;
 }
 
+template <int NC, int TE>
+int launch_pipe1(const KArgs& k, hipStream_t st) {
+  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_pipe2<NC, TE, true>(k, st);
+  return launch_pipe2<NC, TE, false>(k, st);
+}
+
 int launch_pipe(const KArgs& k, hipStream_t st) {
-  if (k.mode == MODE_STEP && k.n_steps > 1) return launch_pipe2<10, 4, true>(k, st);
-  return launch_pipe2<10, 4, false>(k, st);
+  switch (k.p.num_agents) {
+    case 10: return launch_pipe1<10, 4>(k, st);   // (4-env tiles: 1024 workgroups at the metric's 4096 envs, 4 per CU)
+#ifndef CAGPU_FAST
+    case 8: return launch_pipe1<8, 8>(k, st);
+    case 6: return launch_pipe1<6, 10>(k, st);
+    case 5: return launch_pipe1<5, 12>(k, st);
+    case 4: return launch_pipe1<4, 16>(k, st);
+    case 3: return launch_pipe1<3, 21>(k, st);
+    case 2: return launch_pipe1<2, 32>(k, st);
+#endif
+    default: return fail(CA_EUNSUPPORTED, "cagpu: no pipelined instantiation for this agent count%s");
+  }
 }
 
 // Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
@@ -1842,7 +1865,7 @@ int launch_any(const KArgs& k0, void* stream) {
 #ifndef CAGPU_NOPIPE
   if (pipe_eligible(k)) return launch_pipe(k, st);
 #endif
-  if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents == 10, closest_first sorting and a grid of at most 4 x CUs or at least 8 x CUs tiles%s");
+  if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents in {2, 3, 4, 5, 6, 8, 10}, closest_first sorting and a grid of at most 4 x CUs or at least 8 x CUs tiles%s");
   k.tile_envs = ROW / N;
   k.col_stride = (N > 32) ? (CAGPU_CSPAD ? (N | 1) : N) : CS_ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
   // N = 10: tiles of 4 envs instead of 6 while that still gives at most 4 workgroups per CU (all co-resident, evenly

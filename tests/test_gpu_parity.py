@@ -922,7 +922,8 @@ def _assert_same_bits(a, b, what):
 
 @pytest.mark.parametrize("N,E,steps,pipeline", [(10, 3073, 12, True), (10, 4096, 12, True), (10, 4096, 12, False),
                                                 (10, 5200, 8, True), (10, 8200, 6, True), (20, 300, 12, True), (50, 40, 10, True),
-                                                (4, 333, 12, True)])
+                                                (4, 333, 12, True), (4, 333, 12, False), (2, 500, 10, True), (3, 211, 10, True),
+                                                (5, 130, 10, True), (6, 97, 10, True), (8, 250, 10, True)])
 def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
     """CaOut.orca_vel -- the velocity the ORCA phases of the STEP kernel itself chose (branch-free half-planes, divq /
     sqrtq, parallel 1-D programmes + scan, lp3_wave8 / lp3_group / the wave-per-agent programme of N > 16; in the
@@ -938,7 +939,7 @@ def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
     g.set_plugins(nat.POL_RVO)
     cases = table[np.arange(E) % table.shape[0]]
     o.reset(cases)
-    for _ in range(60 if N <= 10 else 25):           # mid-episode: most programmes have violated lines, some infeasible
+    for _ in range(20 if N <= 3 else (60 if N <= 10 else 25)):   # mid-episode: most programmes have violated lines, some infeasible
         o.step()
     _upload(o, g)
     queried = 0
@@ -948,8 +949,8 @@ def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
         o.step()
         g.step()
         kern = nat.lib().cagpu_last_kernel().decode()
-        if N == 10 and pipeline and (E <= 4096 or E >= 8192):
-            assert kern.startswith("ca_pipe_kernel<10, 4, false>"), kern
+        if pipeline and (N in (2, 3, 4, 5, 6, 8) or (N == 10 and (E <= 4096 or E >= 8192))):
+            assert kern.startswith("ca_pipe_kernel<%d, %d, false>" % (N, 4 if N == 10 else 64 // N)), kern
             if t > 0:   # the fast path: every agent that is queried next holds a valid plan
                 assert (g.state["flags"].cpu().numpy().reshape(-1) >> 17 & 1).all()
         else:
