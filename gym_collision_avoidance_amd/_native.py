@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 5   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 6   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -72,7 +72,7 @@ class CaNet(C.Structure):
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_plan")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan")
 
 _lib = None
 
@@ -92,6 +92,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.cagpu_version.restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
+    got = L.cagpu_version()
+    if got != ABI_VERSION:  # a stale or experiment build would silently mis-read the structs above
+        raise CagpuError("%s reports ABI version %d, this binding mirrors version %d of include/cagpu.h -- rebuild "
+                         "(python -m gym_collision_avoidance_amd.build_native)" % (LIB_PATH, got, ABI_VERSION))
     PP, PS, PO, PA = C.POINTER(CaParams), C.POINTER(CaState), C.POINTER(CaOut), C.POINTER(CaAutoReset)
     L.cagpu_reset.argtypes = [PP, PS, PO, _P, _P, _P, _P]
     L.cagpu_step.argtypes = [PP, PS, PO, _P, PA, _P]
@@ -104,16 +108,14 @@ def lib():
                              C.c_float, _P, _P]
     L.cagpu_ga3c.argtypes = [PP, PS, _P, C.POINTER(CaNet), _P, _P, _P]
     L.cagpu_generate_cases.argtypes = [C.c_int64, C.c_int32] + [C.c_double] * 6 + [C.c_uint64, _P, _P, _P]
+    L.cagpu_generate_cases_ragged.argtypes = ([C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32] + [C.c_double] * 4 +
+                                              [C.c_uint64, _P, _P, _P, _P])
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
         if n not in ("cagpu_last_error", "cagpu_last_kernel"):
             getattr(L, n).restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
     L.cagpu_last_kernel.restype = C.c_char_p
-    got = L.cagpu_version()
-    if got != ABI_VERSION:  # a stale or experiment build would silently mis-read the structs above
-        raise CagpuError("%s reports ABI version %d, this binding mirrors version %d of include/cagpu.h -- rebuild "
-                         "(python -m gym_collision_avoidance_amd.build_native)" % (LIB_PATH, got, ABI_VERSION))
     _lib = L
     return L
 

@@ -181,19 +181,40 @@ class BatchedSim(object):
         return ext
 
     def generate_cases(self, num_cases, seed, side_length=4.0, speed_bnds=(0.5, 2.0), radius_bnds=(0.2, 0.8),
-                       return_status=False):
+                       return_status=False, num_agents=None, return_counts=False):
         """`num_cases` random scenarios for this sim's agent count, drawn ON THE DEVICE by cagpu_generate_cases
         (generate_rand_test_case_multi behind test_cases.get_testcase_random, test_cases.py:212-253): float64 device
         tensor [num_cases, N, 6], ready for reset() / set_fixture_table().  `side_length`: a number, or (lo, hi) to draw
-        it per case like the reference's per-agent-count ranges.  Same (seed, case index) -> same scenario."""
-        lo, hi = (side_length, side_length) if np.isscalar(side_length) else side_length
+        it per case.  Same (seed, case index) -> same scenario.
+
+        `num_agents=(lo, hi)`: a RAGGED table (cagpu_generate_cases_ragged) -- the agent count of every case drawn in
+        lo .. hi <= N like the reference's num_agents=None (test_cases.py:224-227), rows past it zero (empty slots; the
+        sim must be built with ragged=1); `side_length` is then a number, (lo, hi), or the reference's list of
+        {"num_agents": [lo, hi), "side_length": [lo, hi]} dicts (config.py:118-131)."""
         out = torch.empty((int(num_cases), self.N, 6), dtype=torch.float64, device=self.device)
         status = torch.zeros((int(num_cases),), dtype=torch.int32, device=self.device)
-        nat.check(self.lib.cagpu_generate_cases(int(num_cases), self.N, float(lo), float(hi), float(speed_bnds[0]),
-                                                float(speed_bnds[1]), float(radius_bnds[0]), float(radius_bnds[1]),
-                                                int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), status.data_ptr(),
-                                                self._stream()))
-        return (out, status) if return_status else out
+        counts = None
+        sp = (float(speed_bnds[0]), float(speed_bnds[1]), float(radius_bnds[0]), float(radius_bnds[1]))
+        if num_agents is None and not isinstance(side_length, list):
+            lo, hi = (side_length, side_length) if np.isscalar(side_length) else side_length
+            nat.check(self.lib.cagpu_generate_cases(int(num_cases), self.N, float(lo), float(hi), *sp,
+                                                    int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), status.data_ptr(),
+                                                    self._stream()))
+        else:
+            n_lo, n_hi = (self.N, self.N) if num_agents is None else (int(num_agents[0]), int(num_agents[1]))
+            if isinstance(side_length, list):
+                rg = [[c["num_agents"][0], c["num_agents"][1], c["side_length"][0], c["side_length"][1]]
+                      for c in side_length]
+            else:
+                lo, hi = (side_length, side_length) if np.isscalar(side_length) else side_length
+                rg = [[0, 1 << 30, lo, hi]]
+            rg = np.ascontiguousarray(rg, dtype=np.float64)
+            counts = torch.zeros((int(num_cases),), dtype=torch.int32, device=self.device)
+            nat.check(self.lib.cagpu_generate_cases_ragged(int(num_cases), self.N, n_lo, n_hi, rg.ctypes.data, len(rg), *sp,
+                                                           int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(),
+                                                           counts.data_ptr(), status.data_ptr(), self._stream()))
+        res = (out,) + ((status,) if return_status else ()) + ((counts,) if return_counts else ())
+        return res if len(res) > 1 else out
 
     def set_fixture_table(self, table, env_id_offset=0, case_stride=None, heading_seed=0):
         """Enable DummyVecEnv-style auto-reset from a fixture table [C,N,6] (vec_env.py:120-128,

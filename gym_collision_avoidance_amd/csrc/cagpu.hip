@@ -2043,24 +2043,63 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   return CA_OK;
 }
 
-int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, double side_hi, double speed_lo,
-                         double speed_hi, double radius_lo, double radius_hi, uint64_t seed, double* cases, int32_t* status,
-                         void* stream) {
+static int generate_impl(int64_t num_cases, int32_t num_agents, int32_t n_min, int32_t n_max, const double* side_ranges,
+                         int32_t n_ranges, double side_lo, double side_hi, double speed_lo, double speed_hi, double radius_lo,
+                         double radius_hi, uint64_t seed, double* cases, int32_t* counts, int32_t* status, void* stream) {
   if (num_cases < 1 || num_agents < 1 || num_agents > 4096) return fail(CA_EINVAL, "cagpu_generate_cases: bad sizes%s");
   if (!cases) return fail(CA_EINVAL, "cagpu_generate_cases: NULL cases%s");
   if (!(side_lo > 0.0) || !(side_hi >= side_lo) || !(speed_lo > 0.0) || !(speed_hi >= speed_lo) || !(radius_lo > 0.0) ||
       !(radius_hi >= radius_lo))
     return fail(CA_EINVAL, "cagpu_generate_cases: bounds must be positive and ordered%s");
   gen::Args a;
+  std::memset(&a, 0, sizeof(a));
   a.cases = cases; a.status = status; a.C = num_cases; a.N = num_agents;
   a.side_lo = side_lo; a.side_hi = side_hi; a.speed_lo = speed_lo; a.speed_hi = speed_hi;
   a.radius_lo = radius_lo; a.radius_hi = radius_hi; a.seed = seed;
   a.max_attempts = 20000;  // the reference loops until a sample is accepted (its square / circle grows 1 % per retry)
+  a.counts = counts;
+  if (n_max > 0) {
+    if (n_min < 1 || n_min > n_max || n_max > num_agents)
+      return fail(CA_EINVAL, "cagpu_generate_cases_ragged: need 1 <= n_min <= n_max <= max_agents%s");
+    a.n_min = n_min; a.n_max = n_max;
+  }
+  if (n_ranges > 0) {
+    if (n_ranges > 8 || !side_ranges) return fail(CA_EINVAL, "cagpu_generate_cases_ragged: at most 8 side ranges%s");
+    for (int r = 0; r < n_ranges; ++r) {
+      for (int k = 0; k < 4; ++k) a.ranges[r][k] = side_ranges[r * 4 + k];
+      if (!(a.ranges[r][2] > 0.0) || !(a.ranges[r][3] >= a.ranges[r][2]))
+        return fail(CA_EINVAL, "cagpu_generate_cases_ragged: side ranges must be positive and ordered%s");
+    }
+    a.n_ranges = n_ranges;
+    // the reference asserts that some entry holds the drawn count (test_cases.py:241)
+    for (int n = (n_max > 0 ? n_min : num_agents); n <= (n_max > 0 ? n_max : num_agents); ++n) {
+      bool held = false;
+      for (int r = 0; r < n_ranges; ++r) held = held || (a.ranges[r][0] <= n && n < a.ranges[r][1]);
+      if (!held) return fail(CA_EINVAL, "cagpu_generate_cases_ragged: an agent count in [n_min, n_max] has no side range%s");
+    }
+  }
   hipLaunchKernelGGL(gen::generate_kernel, dim3(static_cast<unsigned>((num_cases + 63) / 64)), dim3(64), 0,
                      static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
+}
+
+int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, double side_hi, double speed_lo,
+                         double speed_hi, double radius_lo, double radius_hi, uint64_t seed, double* cases, int32_t* status,
+                         void* stream) {
+  return generate_impl(num_cases, num_agents, 0, 0, nullptr, 0, side_lo, side_hi, speed_lo, speed_hi, radius_lo, radius_hi,
+                       seed, cases, nullptr, status, stream);
+}
+
+int cagpu_generate_cases_ragged(int64_t num_cases, int32_t max_agents, int32_t n_min, int32_t n_max,
+                                const double* side_ranges, int32_t n_ranges, double speed_lo, double speed_hi,
+                                double radius_lo, double radius_hi, uint64_t seed, double* cases, int32_t* counts,
+                                int32_t* status, void* stream) {
+  if (n_ranges < 1) return fail(CA_EINVAL, "cagpu_generate_cases_ragged: need at least one side range%s");
+  if (n_max < 1) return fail(CA_EINVAL, "cagpu_generate_cases_ragged: need 1 <= n_min <= n_max <= max_agents%s");
+  return generate_impl(num_cases, max_agents, n_min, n_max, side_ranges, n_ranges, 1.0, 1.0, speed_lo, speed_hi, radius_lo,
+                       radius_hi, seed, cases, counts, status, stream);
 }
 
 int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,

@@ -110,7 +110,9 @@ class CollisionAvoidanceEnv(Env):
         `generate`: dict(num_cases=..., seed=..., side_length=4.0 or (lo, hi), speed_bnds=(0.5, 2.0),
         radius_bnds=(0.2, 0.8)) -- the table is drawn ON THE DEVICE by cagpu_generate_cases (the reference's
         get_testcase_random, test_cases.py:212-253) when reset() builds the batch: training-mode resets then never touch
-        the host.
+        the host.  With `num_agents=(lo, hi)` in the dict every case also draws its own agent count (the reference's
+        num_agents=None; `side_length` may then be the reference's list of {"num_agents", "side_length"} range dicts):
+        a ragged table whose short cases leave their last slots empty.
         `random_headings` (default: `not Config.EVALUATE_MODE`, the reference's rule, test_cases.py:553-559): initial
         headings -- at reset() and at every on-device auto-reset -- are uniform in [-pi, pi) instead of pointing at the
         goal; drawn on the device from `heading_seed`."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 5
+#define CAGPU_VERSION 6
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -266,6 +266,18 @@ int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNe
 int cagpu_generate_cases(int64_t num_cases, int32_t num_agents, double side_lo, double side_hi, double speed_lo,
                          double speed_hi, double radius_lo, double radius_hi, uint64_t seed, double *cases, int32_t *status,
                          void *stream);
+
+/* The same generator for RAGGED tables -- test_cases.get_testcase_random with num_agents=None and a side_length list
+ * (envs/test_cases.py:224-241, the reference's default TEST_CASE_ARGS, config.py:118-131): the agent count of a case is
+ * drawn first, uniform over n_min .. n_max (np.random.randint(2, MAX_NUM_AGENTS_IN_ENVIRONMENT + 1)), then the side
+ * length from every entry of side_ranges (HOST float64 [n_ranges, 4] = count lo, count hi (exclusive), side lo, side hi;
+ * n_ranges <= 8) that holds the count; every count in [n_min, n_max] must be held by an entry (the reference asserts it).
+ * cases: device float64 [num_cases, max_agents, 6]; rows past the drawn count are zero (radius 0 = an empty slot of a
+ * ragged batch, CaParams.ragged).  counts: device int32 [num_cases] or NULL. */
+int cagpu_generate_cases_ragged(int64_t num_cases, int32_t max_agents, int32_t n_min, int32_t n_max,
+                                const double *side_ranges, int32_t n_ranges, double speed_lo, double speed_hi,
+                                double radius_lo, double radius_hi, uint64_t seed, double *cases, int32_t *counts,
+                                int32_t *status, void *stream);
 
 /* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
  * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is

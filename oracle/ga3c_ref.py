@@ -6,9 +6,13 @@ Follows the TF1 graph stored in the reference's checkpoint
 oracle/extract_ga3c_weights.py -- node names in the comments) and the policy wrapper
 gym_collision_avoidance/envs/policies/GA3CCADRLPolicy.py:49-84 + GA3C_CADRL/network.py:7-41.
 
-PARITY UNPINNED for this file: TensorFlow is not installed here, so the reference network cannot be executed; the
-restatement is checked only against the three known-answer cases recorded in SURVEY.md Appendix C and by behaviour
-(agents driven by it reach their goals).  float32 throughout, like the TF graph; summation order is numpy's.
+Pinned (round 3) by oracle/tf_graph_exec.py: a TensorFlow-free executor of the checkpoint's OWN GraphDef (every node of
+the .meta file between the input placeholder and the softmax, while-loop frames and TensorArrays of the dynamic LSTM
+included, weights read from the checkpoint's .data file) whose logits on 256 recorded inputs are committed as
+tests/golden/ga3c_graph.npz (oracle/gen_ga3c_golden.py) -- this restatement must reproduce them (tests/
+test_ga3c_graph_golden.py), together with the three known-answer cases of SURVEY.md Appendix C.  What stays unexecuted
+is TensorFlow's own kernels (not installed here): the executor implements each op from its published definition.
+float32 throughout, like the TF graph; summation order is numpy's.
 """
 import os
 

@@ -3,6 +3,6 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 $@ > gpurun_out/pytest_gpu.log 2>&1
+timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 "$@" > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -40 gpurun_out/pytest_gpu.log

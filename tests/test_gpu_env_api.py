@@ -159,6 +159,30 @@ def test_batched_env_outputs_are_fresh_tensors_and_generated_suite():
     assert a.data_ptr() == b.data_ptr() == zc._sim.obs.data_ptr()
 
 
+def test_generated_ragged_suite_through_the_env_api():
+    """set_fixture_suite(generate=dict(num_agents=(2, 10), side_length=<the reference's range list>)): the reference's
+    default training scenario source (TEST_CASE_ARGS, config.py:118-131 -> test_cases.py:224-241) drawn on the device --
+    every case has its own agent count, the batch is ragged, auto-resets load other counts into the same slots"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    E = 128
+    env = Env(num_envs=E)
+    sides = [{"num_agents": [0, 5], "side_length": [4, 5]}, {"num_agents": [5, 1 << 20], "side_length": [6, 8]}]
+    env.set_fixture_suite(10, "RVO", generate=dict(num_cases=400, seed=9, side_length=sides, num_agents=(2, 10)))
+    obs, _ = env.reset()
+    tab = env._fixture["table"].cpu().numpy()
+    counts = (tab[..., 5] > 0).sum(1)
+    assert env._sim.p.ragged == 1 and set(counts) == set(range(2, 11)) and len(env.agents) == counts[0]
+    fl0 = env._sim.state["flags"].cpu().numpy().astype(np.uint32)
+    assert np.array_equal(((fl0 >> 16 & 1) == 0).sum(1), counts[:E])
+    for _ in range(400):
+        obs, rew, over, _, _ = env.step(None)
+    st = env.episode_stats()
+    assert st["episodes"] > E and np.isfinite(obs.cpu().numpy()).all()
+    assert st["episodes"] == st["collision_episodes"] + st["all_at_goal_episodes"] + st["stuck_episodes"]
+    assert st["all_at_goal_episodes"] > 0.6 * st["episodes"]
+    envtools.default()
+
+
 def test_run_episode_statistics_schema():
     Config, tc, Env = envtools.fresh("Swap4")
     from gym_collision_avoidance_amd.experiments.env_utils import create_env, run_episode

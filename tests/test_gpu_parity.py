@@ -820,6 +820,48 @@ def test_device_scenarios_match_host_generator(N, side, seed):
     assert not np.array_equal(other, got[:17])
 
 
+def test_device_ragged_scenarios_match_host_generator():
+    """cagpu_generate_cases_ragged (get_testcase_random with num_agents=None and the reference's default side_length
+    list, test_cases.py:224-241 / config.py:118-131): every case draws its agent count, then its side length from the
+    range that holds the count; against the host generator under the same Philox stream, rows past the count zero"""
+    nat, core, orc = _mods()
+    from tests.test_host_logic import host_cases_from_philox
+    C_, N = 128, 10
+    sides = [{"num_agents": [0, 5], "side_length": [4, 5]}, {"num_agents": [5, np.inf], "side_length": [6, 8]}]
+    dev_sides = [{"num_agents": [0, 5], "side_length": [4, 5]}, {"num_agents": [5, 1 << 20], "side_length": [6, 8]}]
+    g = core.BatchedSim(core.make_params(4, N, ragged=1))
+    got, status, counts = g.generate_cases(C_, 77, side_length=dev_sides, num_agents=(2, N), return_status=True,
+                                           return_counts=True)
+    torch.cuda.synchronize()
+    got, status, counts = got.cpu().numpy(), status.cpu().numpy(), counts.cpu().numpy()
+    want, kinds = host_cases_from_philox(77, C_, N, sides, num_agents=(2, N))
+    assert not status.any() and set(kinds) == {"swap", "circle", "rand"}
+    assert np.array_equal(counts, (want[..., 5] > 0).sum(1)) and set(counts) == set(range(2, N + 1))
+    assert np.array_equal(got[..., 5] > 0, want[..., 5] > 0) and not got[got[..., 5] <= 0].any()
+    same = np.abs(got - want).reshape(C_, -1).max(axis=1) <= 1e-9
+    assert same.mean() >= 0.97, (same.mean(), [k for k, s_ in zip(kinds, same) if not s_])
+    # as the on-device auto-reset table of a ragged batch: absent slots stay absent through resets, nothing blows up
+    sim = core.BatchedSim(core.make_params(256, N, ragged=1))
+    table = g.generate_cases(512, 78, side_length=dev_sides, num_agents=(2, N))
+    sim.set_plugins(nat.POL_RVO)
+    sim.reset(table[:256])
+    sim.set_fixture_table(table)
+    for _ in range(300):
+        sim.step()
+    torch.cuda.synchronize()
+    fl = sim.state["flags"].cpu().numpy().astype(np.uint32)
+    nres = sim.state["reset_count"].cpu().numpy()
+    tab = table.cpu().numpy()
+    assert np.isfinite(sim.state["pos_x"].cpu().numpy()).all() and nres.max() >= 1
+    case = (np.arange(256) + nres.astype(np.int64) * 256) % 512
+    assert np.array_equal((fl >> 16 & 1) == 1, tab[case][..., 5] <= 0)
+    # bad arguments are refused: a count range outside the side ranges, a count above the table width
+    with pytest.raises(nat.CagpuError):
+        g.generate_cases(4, 1, side_length=[{"num_agents": [0, 5], "side_length": [4, 5]}], num_agents=(2, N))
+    with pytest.raises(nat.CagpuError):
+        g.generate_cases(4, 1, side_length=4.0, num_agents=(2, N + 1))
+
+
 def test_device_scenarios_statistics_and_training_reset():
     """4096 generated 10-agent scenarios: family mix 15 / 15 / 70 %, the reference's clearance and trip-length rules,
     speed = max of two uniforms, uniform radii; then used as the on-device auto-reset table of a stepping batch"""

@@ -257,15 +257,30 @@ def test_random_scenarios_match_the_reference_bit_for_bit():
     envtools.default()
 
 
-def host_cases_from_philox(seed, num_cases, n, side, speed=(0.5, 2.0), radius=(0.2, 0.8)):
+def host_cases_from_philox(seed, num_cases, n, side, speed=(0.5, 2.0), radius=(0.2, 0.8), num_agents=None):
     """the HOST generator (bit-identical to the reference under np.random) driven by the device generator's uniform
-    stream (oracle/philox_ref.py): what cagpu_generate_cases must return.  -> (cases [C, n, 6], family names)"""
+    stream (oracle/philox_ref.py): what cagpu_generate_cases must return.  -> (cases [C, n, 6], family names).
+    `num_agents=(lo, hi)`: the ragged form (cagpu_generate_cases_ragged) -- the count first, then the side length from
+    the reference's list of range dicts (test_cases.py:224-241), rows past the count zero"""
     from oracle.philox_ref import PhiloxStream
     from gym_collision_avoidance_amd.envs import scenario_generator as sg
 
     class _NP(object):  # what scenario_generator reads from numpy, with `random` swapped for the Philox stream
         def __getattr__(self, name):
             return getattr(np, name)
+
+    def preamble(st):  # the draws before the family dice
+        k = n
+        if num_agents is not None:
+            k = min(num_agents[0] + int(st.rand() * (num_agents[1] - num_agents[0] + 1)), num_agents[1])
+        s = side
+        if isinstance(side, list):
+            for comp in side:
+                if comp["num_agents"][0] <= k < comp["num_agents"][1]:
+                    s = comp["side_length"][0] + (comp["side_length"][1] - comp["side_length"][0]) * st.rand()
+        elif not np.isscalar(side):
+            s = side[0] + (side[1] - side[0]) * st.rand()
+        return k, s
     out, kinds = [], []
     real = sg.np
     try:
@@ -274,13 +289,14 @@ def host_cases_from_philox(seed, num_cases, n, side, speed=(0.5, 2.0), radius=(0
             shim = _NP()
             shim.random = st
             sg.np = shim
-            s = side if np.isscalar(side) else side[0] + (side[1] - side[0]) * st.rand()
+            k, s = preamble(st)
             dice = PhiloxStream(seed, c)
-            if not np.isscalar(side):
-                dice.rand()
+            preamble(dice)
             d = dice.rand()
             kinds.append("swap" if d < 0.15 else "circle" if d < 0.3 else "rand")
-            out.append(sg.generate_rand_test_case_multi(n, s, list(speed), list(radius)))
+            rows = np.zeros((n, 6))
+            rows[:k] = sg.generate_rand_test_case_multi(k, s, list(speed), list(radius))
+            out.append(rows)
     finally:
         sg.np = real
     return np.array(out), kinds
