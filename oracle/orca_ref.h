@@ -164,7 +164,7 @@ struct LpStats {
 };
 static const float kLpStatsMargins[8] = {0.0f, 0.02f, 0.05f, 0.1f, 0.2f, 0.3f, 0.5f, 1.0f};
 static LpStats g_lp_stats;
-static std::vector<int> g_lp_log;  // per query: number of lines linearProgram3 acted on (-1: linearProgram2 was feasible)
+static std::vector<int> g_lp_log;  // per query: number of lines linearProgram3 acted on + 256 x (lines from the failing one on); -1: linearProgram2 was feasible
 #endif
 static inline size_t lp2(const std::vector<HalfPlane>& L, float radius, Vec opt, bool dir_opt, Vec& res) {
   if (dir_opt) res = scl(radius, opt);  // opt * radius (commutative per component)
@@ -234,7 +234,7 @@ static inline void lp3(const std::vector<HalfPlane>& L, size_t begin, float radi
   float depth = 0.0f;
   std::vector<HalfPlane> P;
 #ifdef ORCA_REF_STATS
-  g_lp_log.push_back(0);
+  g_lp_log.push_back(static_cast<int>((L.size() - begin) << 8));  // (bits 8 ..: lines from the failing one on)
 #endif
   for (size_t i = begin; i < L.size(); ++i) {
     if (cross(L[i].dir, sub(L[i].pt, res)) > depth) {

@@ -32,17 +32,20 @@ for rep in range(20):
     rows.append(np.frombuffer(buf, dtype=np.uint64).reshape(1024, 32)[:E // 4].astype(np.int64).copy())
 print(lib.cagpu_last_kernel().decode())
 tick = 0.01
-W0 = ["start", "loaded", "B_A", "moved(pre-move pt)", "published", "B_P", "B_1", "A3 done", "B_2", "A4 done", "B_3", "B_4", "stored"]
-W4 = ["B_P", "P2 done", "B_1", "P2b done", "B_2", "scan done", "B_3", "lp3 done", "after B_4", "post done"]
+W0 = ["start", "loaded", "B_A", "moved(pre-move pt)", "published", "B_P", "P3 arrived", "A3 done", "(A3 done)", "A4 done", "A4 signalled", "(same)", "stored"]
+W4 = ["B_P", "P2 done", "P2 of all waves", "P2b done", "P2b of all waves", "scan done", "queue seen", "lp3 done", "lp3 of all + A4 seen", "post done"]
 dur, span, seg0, seg4, slow0, slow4, n3s, lives = [], [], [], [], [], [], [], []
+skew, lastdur, laststart = [], [], []
 for a in rows:
     t0 = a[:, 0]
     end = np.maximum(a[:, 12], a[:, 25])
     d = (end - t0) * tick
     dur.append(d)
     span.append((end.max() - t0.min()) * tick)
+    skew.append((np.percentile(t0, [50, 90, 99, 100]) - t0.min()) * tick)
+    kk = np.argsort(end)[-5:]
+    lastdur.append(d[kk]); laststart.append((t0[kk] - t0.min()) * tick)
     w0 = a[:, 0:13].copy()
-    w0[:, 11] = np.where(a[:, 13] & 0xFF, w0[:, 11], w0[:, 10])     # (no B_4 stamp path is still stamped: same time)
     s0 = np.diff(w0, axis=1) * tick
     w4 = a[:, 16:26].copy()
     noq = (a[:, 13] & 0xFF) == 0
@@ -56,6 +59,7 @@ dur = np.concatenate(dur); seg0 = np.concatenate(seg0); seg4 = np.concatenate(se
 slow0 = np.concatenate(slow0); slow4 = np.concatenate(slow4); n3s = np.concatenate(n3s); lives = np.concatenate(lives)
 print("workgroup duration (start -> last store): mean %.2f p50 %.2f p90 %.2f p99 %.2f p99.9 %.2f max %.2f us; first start -> last end per launch: mean %.2f" % (
     dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), np.percentile(dur, 99.9), dur.max(), np.mean(span)))
+print("start skew after the first workgroup: p50 %.2f p90 %.2f p99 %.2f max %.2f us; the 5 last-finishing workgroups of a launch: started at +%.2f, ran %.2f us (mean)" % (tuple(np.mean(skew, axis=0)) + (np.mean(laststart), np.mean(lastdur))))
 print("wave 0 segments (mean all | mean of the 10 last-finishing workgroups per launch):")
 for i in range(12):
     print("   %-22s -> %-22s %6.2f | %6.2f" % (W0[i], W0[i + 1], seg0[:, i].mean(), slow0[:, i].mean()))
