@@ -240,6 +240,7 @@ static inline void lp3(const std::vector<HalfPlane>& L, size_t begin, float radi
     if (cross(L[i].dir, sub(L[i].pt, res)) > depth) {
 #ifdef ORCA_REF_STATS
       g_lp_log.back() += 1;
+      if ((g_lp_log.back() & 0xFF) >= 2) g_lp_log.back() |= 1 << (16 + static_cast<int>(i - begin));  // (bits 16 ..: which later lines acted)
 #endif
       P.clear();
       for (size_t j = 0; j < i; ++j) {

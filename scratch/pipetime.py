@@ -36,6 +36,7 @@ W0 = ["start", "loaded", "B_A", "moved(pre-move pt)", "published", "B_P", "P3 ar
 W4 = ["B_P", "P2 done", "P2 of all waves", "P2b done", "P2b of all waves", "scan done", "queue seen", "lp3 done", "lp3 of all + A4 seen", "post done"]
 dur, span, seg0, seg4, slow0, slow4, n3s, lives = [], [], [], [], [], [], [], []
 skew, lastdur, laststart = [], [], []
+acts, actmax, slow_info = [], [], []
 for a in rows:
     t0 = a[:, 0]
     end = np.maximum(a[:, 12], a[:, 25])
@@ -55,6 +56,8 @@ for a in rows:
     k = np.argsort(end)[-10:]
     slow0.append(s0[k]); slow4.append(s4[k])
     n3s.append(a[:, 13] & 0xFF); lives.append((a[:, 13] >> 8) & 0xFF)
+    acts.append((a[:, 13] >> 24) & 0xFF); actmax.append((a[:, 13] >> 32) & 0xFF)
+    slow_info.append(np.stack([a[k, 13] & 0xFF, (a[k, 13] >> 8) & 0xFF, (a[k, 13] >> 24) & 0xFF, (a[k, 13] >> 32) & 0xFF, (a[k, 13] >> 16) & 0xFF], axis=1))
 dur = np.concatenate(dur); seg0 = np.concatenate(seg0); seg4 = np.concatenate(seg4)
 slow0 = np.concatenate(slow0); slow4 = np.concatenate(slow4); n3s = np.concatenate(n3s); lives = np.concatenate(lives)
 print("workgroup duration (start -> last store): mean %.2f p50 %.2f p90 %.2f p99 %.2f p99.9 %.2f max %.2f us; first start -> last end per launch: mean %.2f" % (
@@ -70,6 +73,12 @@ for lo, hi in ((0, 0), (1, 1), (2, 2), (3, 4), (5, 99)):
     m = (n3s >= lo) & (n3s <= hi)
     if m.any():
         print("   lp3 queue %d..%d: %5.1f %% of the workgroups, duration mean %.2f p90 %.2f" % (lo, hi, 100 * m.mean(), dur[m].mean(), np.percentile(dur[m], 90)))
+actmax = np.concatenate(actmax); slow_info = np.concatenate(slow_info)
+for v in range(0, 5):
+    m = actmax == v
+    if m.any():
+        print("   most lines linearProgram3 acted on for one agent = %d: %5.1f %%, duration mean %.2f p90 %.2f" % (v, 100 * m.mean(), dur[m].mean(), np.percentile(dur[m], 90)))
+print("the 10 last-finishing workgroups per launch: queue length mean %.2f, planned agents mean %.1f (> 28: %.0f %%), acted lines sum %.2f max-per-agent hist %s, resets %.0f %%" % (slow_info[:, 0].mean(), slow_info[:, 1].mean(), 100 * (slow_info[:, 1] > 28).mean(), slow_info[:, 2].mean(), np.round(np.bincount(slow_info[:, 3], minlength=5) / len(slow_info), 2), 100 * (slow_info[:, 4] > 0).mean()))
 for lo, hi in ((0, 16), (17, 24), (25, 28), (29, 40)):
     m = (lives >= lo) & (lives <= hi)
     if m.any():
