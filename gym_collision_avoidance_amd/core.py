@@ -90,6 +90,11 @@ class BatchedSim(object):
                              game_over=self.game_over.data_ptr(),
                              actions=self.actions.data_ptr() if record_actions else None,
                              orca_vel=self.orca_vel.data_ptr() if record_actions else None)
+        # fresh_outputs: every step / rollout writes obs, rewards, done and game_over into NEWLY allocated tensors (the
+        # previous ones stay valid and belong to whoever holds them: the env API's "fresh arrays every step" without a
+        # copy kernel).  Every element of the four outputs is rewritten by every step launch
+        # (tests/test_gpu_parity.py::test_step_rewrites_every_output_element), so nothing is carried over in them.
+        self.fresh_outputs = False
         self._ar = None
         self._fast_args = None    # prebuilt ctypes arguments of the external-action-free step (see step())
         self._table = None
@@ -299,6 +304,13 @@ class BatchedSim(object):
                                            C.byref(self._scan), self._stream()))
         return self.scan
 
+    def _new_outputs(self):
+        co = self._co
+        self.obs = torch.empty_like(self.obs); co.obs = self.obs.data_ptr()
+        self.rewards = torch.empty_like(self.rewards); co.rewards = self.rewards.data_ptr()
+        self.done = torch.empty_like(self.done); co.done = self.done.data_ptr()
+        self.game_over = torch.empty_like(self.game_over); co.game_over = self.game_over.data_ptr()
+
     def step(self, ext_actions=None):
         if ext_actions is None and not self._has_ga3c:
             # env.step(None) with built-in policies only (env_utils.py:50): the per-step host path is one ctypes call
@@ -312,6 +324,8 @@ class BatchedSim(object):
                 else:
                     fa = (self.lib.cagpu_step, (C.byref(self.p), C.byref(self._cs), C.byref(self._co), None, ar))
                 self._fast_args = fa
+            if self.fresh_outputs:
+                self._new_outputs()
             rc = fa[0](*fa[1], torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 nat.check(rc)
@@ -325,6 +339,8 @@ class BatchedSim(object):
                     self._ga3c_ext = torch.zeros((self.E, self.N, 2), dtype=torch.float64, device=self.device)
                 self._ga3c_ext.copy_(e)
             e = self.ga3c(None if e is None else self._ga3c_ext)
+        if self.fresh_outputs:
+            self._new_outputs()
         if self._map is not None:
             nat.check(self.lib.cagpu_step_map(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
                                               None if e is None else e.data_ptr(),
@@ -343,6 +359,8 @@ class BatchedSim(object):
                 self.step(ext_actions)
             return self.obs, self.rewards, self.game_over
         e = self._dev(ext_actions, torch.float64)
+        if self.fresh_outputs:
+            self._new_outputs()
         nat.check(self.lib.cagpu_rollout(C.byref(self.p), C.byref(self._cs), C.byref(self._co),
                                          None if e is None else e.data_ptr(),
                                          None if self._ar is None else C.byref(self._ar), int(n_steps),

@@ -365,6 +365,10 @@ class CollisionAvoidanceEnv(Env):
                     agent._bind(self, e, a_idx)
         self._snap, self._obs_np, self._scan_np = None, None, None
         self._learning_info = None
+        # batched, not zero_copy: every step writes into newly allocated output tensors, so what step() returns is the
+        # caller's to keep without a copy kernel -- unless something of ours reads the observation back later (the
+        # GA3C-CADRL query, a host-side policy): then the outputs are copies and ours stay private
+        sim.fresh_outputs = E > 1 and not self.zero_copy and not nets and not self._host_policies
         if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
             sm = self.static_map_filename
             if isinstance(sm, list) and sm and isinstance(sm[0], str):
@@ -428,8 +432,9 @@ class CollisionAvoidanceEnv(Env):
         self._snap = None
 
     def _out(self, t):
-        """a device output as handed to the caller: the persistent buffer itself (zero_copy) or a fresh copy"""
-        return t if self.zero_copy else t.clone()
+        """a device output as handed to the caller: the simulator's buffer itself -- zero_copy, or a batch whose every
+        step writes into newly allocated tensors (core.BatchedSim.fresh_outputs) -- or a copy"""
+        return t if (self.zero_copy or self._sim.fresh_outputs) else t.clone()
 
     def _zero_obs(self):
         return {s: np.zeros(Config.STATE_INFO_DICT[s]["size"], dtype=Config.STATE_INFO_DICT[s]["dtype"])

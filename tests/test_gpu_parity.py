@@ -820,6 +820,53 @@ def test_device_scenarios_match_host_generator(N, side, seed):
     assert not np.array_equal(other, got[:17])
 
 
+@pytest.mark.parametrize("N,E,pipeline,ragged", [(10, 4096, True, 0), (10, 3073, True, 0), (10, 300, False, 0), (4, 333, True, 0),
+                                                  (4, 200, True, 1), (20, 130, True, 0), (50, 24, True, 0)])
+def test_step_rewrites_every_output_element(N, E, pipeline, ragged):
+    """Every step launch writes EVERY element of obs, rewards, done and game_over (done agents, empty slots of a ragged
+    batch, envs that auto-reset in the step, the last tile of a batch included): the outputs carry nothing from one step
+    to the next, which is what lets BatchedSim.fresh_outputs hand each step newly allocated tensors instead of copies"""
+    nat, core, orc = _mods()
+    from tests import golden_util as gu
+    table = gu.suite_cases("ragged4") if ragged else np.load(
+        os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
+    C_ = len(table)
+    g = core.BatchedSim(core.make_params(E, N, ragged=ragged), pipeline=pipeline)
+    g.set_plugins(nat.POL_RVO)
+    g.reset(table[np.arange(E) % C_])
+    g.set_fixture_table(table)
+    poisoned = 0
+    for t in range(260):
+        if t % 20 == 19 or t > 250:  # (also steps in which envs auto-reset: a 4-agent case ends after ~60 steps)
+            g.obs.fill_(float("nan")); g.rewards.fill_(float("nan")); g.done.fill_(0xFF); g.game_over.fill_(0xFF)
+            poisoned += 1
+        g.step()
+        if t % 20 == 19 or t > 250:
+            torch.cuda.synchronize()
+            assert not torch.isnan(g.obs).any(), t
+            assert not torch.isnan(g.rewards).any(), t
+            assert int(g.done.max()) <= 1 and int(g.game_over.max()) <= 1, t
+    assert poisoned > 15 and (N > 20 or int(g.state["reset_count"].max()) >= 1)  # (a 50-agent crowd takes longer)
+    # the same through fresh_outputs: new tensors every step, the old ones keep their contents, the state advances the same
+    h = core.BatchedSim(core.make_params(E, N, ragged=ragged), pipeline=pipeline)
+    h.set_plugins(nat.POL_RVO)
+    h.reset(table[np.arange(E) % C_])
+    h.set_fixture_table(table)
+    h.fresh_outputs = True
+    kept = []
+    for t in range(260):
+        o_, r_, go_ = h.step()
+        if t in (3, 100, 259):
+            kept.append((o_, o_.clone(), r_, r_.clone()))
+    torch.cuda.synchronize()
+    assert len({k_[0].data_ptr() for k_ in kept}) == 3
+    for o_, oc, r_, rc in kept:
+        assert torch.equal(o_, oc) and torch.equal(r_, rc)
+    assert torch.equal(h.obs, g.obs) and torch.equal(h.rewards, g.rewards) and torch.equal(h.done, g.done)
+    for n in F64:
+        assert torch.equal(h.state[n], g.state[n]), n
+
+
 def test_device_ragged_scenarios_match_host_generator():
     """cagpu_generate_cases_ragged (get_testcase_random with num_agents=None and the reference's default side_length
     list, test_cases.py:224-241 / config.py:118-131): every case draws its agent count, then its side length from the
