@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 6   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 7   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -35,7 +35,7 @@ class CaParams(C.Structure):
 
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
                 "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
-                "reset_count", "env_stats", "next_action")
+                "reset_count", "env_stats", "next_action", "turning_dir")
 OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel")
 
 

@@ -15,7 +15,7 @@ import torch
 from . import _native as nat
 
 _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
-        "time_remaining", "t", "slt", "ep_reward")
+        "time_remaining", "t", "slt", "ep_reward", "turning_dir")
 STAT_NAMES = ("episodes", "collision_episodes", "all_at_goal_episodes", "stuck_episodes", "sum_steps",
               "sum_total_reward", "sum_time_to_goal", "sum_extra_time_to_goal")
 

@@ -583,7 +583,15 @@ struct Lane {  // per-lane registers of one agent (wave 0)
   float act0, act1;
   uint32_t flags;
   int32_t step_num;
+  double td;  // Agent.turning_dir (only where CaState.turning_dir is given)
 };
+
+// Agent.turning_dir after UnicycleDynamics.step turned the agent to heading `nh` (UnicycleDynamics.py:41-47)
+__device__ __forceinline__ double turning_dir_next(const double td, const double nh) {
+  if (fabs(td) < 1e-5) return 0.11 * ((nh > 0.0) - (nh < 0.0));
+  if (td * nh < 0.0) return fmax(-kPi, fmin(kPi, -td + nh));
+  return ((td > 0.0) - (td < 0.0)) * fmax(0.0, fabs(td) - 0.1);
+}
 
 // test_cases.py:545-557 + agent.py:59-138
 // (the heading travels by value: a pointer to a local kept a 16-byte scratch object alive in every instantiation)
@@ -600,6 +608,7 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const bool 
   r.tr = tr;
   r.t = 0.0;
   r.epr = 0.0;
+  r.td = 0.0;
   r.act0 = r.act1 = 0.f;
   r.step_num = 0;
   r.flags &= ~(0x3Fu | CA_ABSENT | CA_PLAN_VALID);
@@ -687,10 +696,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   // ---- load my agent
   Lane r;
   r.px = r.py = r.vx = r.vy = r.heading = r.gx = r.gy = 0.0;
-  r.rad = r.ps = 1.0; r.tr = r.t = r.slt = r.epr = 0.0;
+  r.rad = r.ps = 1.0; r.tr = r.t = r.slt = r.epr = 0.0; r.td = 0.0;
   r.act0 = r.act1 = 0.f; r.flags = CA_DONE | CA_AT_GOAL; r.step_num = 0;
   int ep_step = 0, reset_cnt = 0;
   if (active) {
+    if (k.s.turning_dir) r.td = k.s.turning_dir[i];
     r.px = k.s.pos_x[i]; r.py = k.s.pos_y[i]; r.vx = k.s.vel_x[i]; r.vy = k.s.vel_y[i];
     r.heading = k.s.heading[i]; r.gx = k.s.goal_x[i]; r.gy = k.s.goal_y[i];
     r.rad = k.s.radius[i]; r.ps = k.s.pref_speed[i]; r.tr = k.s.time_remaining[i]; r.t = k.s.t[i];
@@ -1110,6 +1120,7 @@ LP1_UNROLL
               r.vx = a0 * cs;
               r.vy = a0 * sn;
               r.heading = nh;
+              if (dyn == CA_DYN_UNICYCLE) r.td = turning_dir_next(r.td, nh);
             }
             const double qx = r.px - r.gx, qy = r.py - r.gy;
             if (qx * qx + qy * qy <= p.near_goal_threshold * p.near_goal_threshold) r.flags |= CA_AT_GOAL;
@@ -1551,6 +1562,7 @@ LP1_UNROLL
     ka->s.pos_x[i] = r.px; ka->s.pos_y[i] = r.py; ka->s.vel_x[i] = r.vx; ka->s.vel_y[i] = r.vy;
     ka->s.heading[i] = r.heading; ka->s.time_remaining[i] = r.tr; ka->s.t[i] = r.t;
     ka->s.ep_reward[i] = r.epr;
+    if (ka->s.turning_dir) ka->s.turning_dir[i] = r.td;
     if (statics_dirty) {
       ka->s.goal_x[i] = r.gx; ka->s.goal_y[i] = r.gy;
       ka->s.radius[i] = r.rad; ka->s.pref_speed[i] = r.ps; ka->s.slt[i] = r.slt;

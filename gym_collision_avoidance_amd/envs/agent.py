@@ -89,7 +89,7 @@ class Agent(object):
         unbound = {"pos_x": i["px"], "pos_y": i["py"], "goal_x": i["gx"], "goal_y": i["gy"], "vel_x": 0.0,
                    "vel_y": 0.0, "heading": i["heading"], "radius": i["radius"], "pref_speed": i["pref_speed"],
                    "t": 0.0, "slt": slt, "time_remaining": max(Config.MAX_TIME_RATIO * slt, self.dt_nominal),
-                   "flags": 0, "step_num": 0, "ep_reward": 0.0, "last_action": np.zeros(2, np.float32)}
+                   "flags": 0, "step_num": 0, "ep_reward": 0.0, "turning_dir": 0.0, "last_action": np.zeros(2, np.float32)}
         return unbound[name]
 
     def _flag(self, bit):
@@ -105,6 +105,7 @@ class Agent(object):
     time_remaining_to_reach_goal = property(lambda self: float(self._s("time_remaining")))
     straight_line_time_to_reach_goal = property(lambda self: float(self._s("slt")))
     step_num = property(lambda self: int(self._s("step_num")))
+    turning_dir = property(lambda self: float(self._s("turning_dir")))  # (agent.py:133; UnicycleDynamics.py:41-47)
     is_at_goal = property(lambda self: self._flag(nat.AT_GOAL))
     was_at_goal_already = property(lambda self: self._flag(nat.WAS_AT_GOAL))
     in_collision = property(lambda self: self._flag(nat.IN_COLLISION))
@@ -241,7 +242,7 @@ class Agent(object):
         snap = AgentSnapshot()
         for name in ("pos_global_frame", "vel_global_frame", "goal_global_frame", "heading_global_frame", "radius",
                      "pref_speed", "t", "time_remaining_to_reach_goal", "straight_line_time_to_reach_goal",
-                     "step_num", "is_at_goal", "was_at_goal_already", "in_collision", "was_in_collision_already",
+                     "step_num", "turning_dir", "is_at_goal", "was_at_goal_already", "in_collision", "was_in_collision_already",
                      "ran_out_of_time", "is_done", "dist_to_goal", "heading_ego_frame", "id",
                      "global_state_history"):
             setattr(snap, name, getattr(self, name))

@@ -33,7 +33,7 @@ _BUILTIN_POLICIES = (RVOPolicy, NonCooperativePolicy, StaticPolicy, ExternalPoli
 _SORT = {"closest_first": nat.SORT_CLOSEST_FIRST, "closest_last": nat.SORT_CLOSEST_LAST,
          "time_to_impact": nat.SORT_TIME_TO_IMPACT}
 _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed", "time_remaining",
-        "t", "slt", "ep_reward")
+        "t", "slt", "ep_reward", "turning_dir")
 
 
 class CollisionAvoidanceEnv(Env):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 6
+#define CAGPU_VERSION 7
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -131,6 +131,9 @@ typedef struct CaState {
                                   starts at the move.  Same arithmetic on the same inputs: results are bit-identical to
                                   next_action == NULL.  Agents without a valid plan (after a reset, after the host wrote
                                   the state, external / learning policies) are queried at the start of the step as before. */
+  double *turning_dir;         /* [E*N] or NULL (not maintained).  Agent.turning_dir: the CADRL value network's turning
+                                  memory, updated by UnicycleDynamics.step only (UnicycleDynamics.py:41-47), zeroed by
+                                  Agent.reset (agent.py:133) */
 } CaState;
 
 /* Device pointers to what a step hands back (collision_avoidance_env.py:225-234). */

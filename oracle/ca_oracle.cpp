@@ -224,6 +224,7 @@ void reset_env(const OrcParams& p, const OrcState& s, int e, const double* cs /*
     s.time_remaining[i] = tr;
     s.t[i] = 0.0;
     s.ep_reward[i] = 0.0;
+    s.turning_dir[i] = 0.0;  // agent.py:133
     s.last_action[2 * i] = s.last_action[2 * i + 1] = 0.f;
     s.step_num[i] = 0;
     s.flags[i] &= (ORC_IS_LEARNING | ORC_STILL_LEARNING);
@@ -374,6 +375,12 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
       s.vel_x[i] = a0 * c;  // :34-35
       s.vel_y[i] = a0 * sn;
       s.heading[i] = nh;  // :39
+      if (s.dynamics[i] == ORC_DYN_UNICYCLE) {  // :41-47 (UnicycleDynamicsMaxTurnRate.py has no such block)
+        double& td = s.turning_dir[i];
+        if (std::fabs(td) < 1e-5) td = 0.11 * ((nh > 0.0) - (nh < 0.0));
+        else if (td * nh < 0.0) td = std::max(-kPi, std::min(kPi, -td + nh));
+        else td = ((td > 0.0) - (td < 0.0)) * std::max(0.0, std::fabs(td) - 0.1);
+      }
     }
     const double gx = s.pos_x[i] - s.goal_x[i], gy = s.pos_y[i] - s.goal_y[i];
     if (gx * gx + gy * gy <= p.near_goal_threshold * p.near_goal_threshold) f |= ORC_AT_GOAL;  // :150-153
@@ -475,7 +482,7 @@ void episode_stats(const OrcParams& p, const OrcState& s, int e) {
 
 extern "C" {
 
-int ca_oracle_version(void) { return 2; }
+int ca_oracle_version(void) { return 3; }
 
 double ca_oracle_round2(double x) { return round2(x); }
 

@@ -59,6 +59,7 @@ typedef struct {
 typedef struct {
   double *pos_x, *pos_y, *vel_x, *vel_y, *heading, *goal_x, *goal_y, *radius, *pref_speed;
   double *time_remaining, *t, *slt /* straight_line_time_to_reach_goal */, *ep_reward;
+  double *turning_dir; /* Agent.turning_dir (agent.py:133; UnicycleDynamics.py:41-47) */
   float *last_action;  /* [.,2] past_actions[0] (agent.py:212-213) */
   uint32_t *flags;
   int32_t *policy, *dynamics, *step_num;

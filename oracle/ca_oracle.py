@@ -39,7 +39,7 @@ class OrcParams(C.Structure):
 
 
 _STATE_F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
-              "time_remaining", "t", "slt", "ep_reward")
+              "time_remaining", "t", "slt", "ep_reward", "turning_dir")
 
 
 class OrcState(C.Structure):

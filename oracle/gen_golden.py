@@ -96,7 +96,7 @@ def _run_episode(env, agents, Config, ext_fn, max_steps):
     states = Config.STATES_IN_OBS
     st, fl = _snapshot(env.agents)
     rec = dict(state=[st], flags=[fl], obs=[_obs_array(obs, env.agents, states)], rewards=[], done=[], game_over=[],
-               ext=[])
+               ext=[], turning=[[a.turning_dir for a in env.agents]])
     laser = "laserscan" in states
     if laser:
         rec["laser"] = [_laser_idx(obs, env.agents)]
@@ -114,6 +114,7 @@ def _run_episode(env, agents, Config, ext_fn, max_steps):
         rec["done"].append(np.array([info["which_agents_done"][a.id] for a in env.agents], dtype=np.uint8))
         rec["game_over"].append(bool(over))
         rec["ext"].append(ext)
+        rec["turning"].append([a.turning_dir for a in env.agents])  # UnicycleDynamics.py:41-47
         if laser:
             rec["laser"].append(_laser_idx(obs, env.agents))
         if over:

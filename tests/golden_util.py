@@ -20,6 +20,7 @@ class Episode(object):
         self.state, self.flags, self.obs = g("state"), g("flags"), g("obs")
         self.rewards, self.done, self.game_over, self.ext = g("rewards"), g("done"), g("game_over"), g("ext")
         self.policy, self.dynamics = g("policy"), g("dynamics")
+        self.turning = g("turning")  # [T+1, N] Agent.turning_dir (UnicycleDynamics.py:41-47)
         self.laser = z["c%d_laser" % c] if ("c%d_laser" % c) in z else None
         self.static_map = z["static_map"] if "static_map" in z else None
         self.T = self.rewards.shape[0]

@@ -65,6 +65,8 @@ def test_env_api_replays_reference_episode(name):
                 assert (a.is_at_goal, a.in_collision, a.ran_out_of_time, a.is_done) == \
                        (bool(f & 1), bool(f & 4), bool(f & 16), bool(f & 32))
                 assert abs(a.t - ep.col(t + 1, "t")[i]) < 1e-9
+                # Agent.turning_dir (UnicycleDynamics.py:41-47), kept on the device: a sign test on the new heading
+                assert abs(a.turning_dir - ep.turning[t + 1][i]) < 1e-5, ("turning_dir", t, i)
         assert env.episode_step_number == ep.T
 
 

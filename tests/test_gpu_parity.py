@@ -18,7 +18,7 @@ TOL = 1e-5
 MASK = 0x3F
 SORT = {"closest_first": 0, "closest_last": 1, "time_to_impact": 2}
 F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
-       "time_remaining", "t", "slt", "ep_reward")
+       "time_remaining", "t", "slt", "ep_reward", "turning_dir")
 
 
 def _mods():
@@ -79,6 +79,12 @@ def _compare(o, g, tol=TOL, what=""):
             # representative of the SAME heading (seen with agents driving exactly along -x), so compare modulo 2 pi
             d = np.abs((gs[n] - o.s[n] + np.pi) % (2 * np.pi) - np.pi)
             assert d.max() <= tol, "heading %s: %g" % (what, d.max())
+            continue
+        if n == "turning_dir":  # branches on the SIGN of the new heading (UnicycleDynamics.py:41-47): an agent whose heading
+            # sits at the wrap boundary (+-pi: see above) or at 0 within an ulp may take the other branch -- a handful of agents
+            # in the fuzzed configurations, none in the reference-recorded episodes (tests/test_gpu_env_api.py)
+            bad = np.abs(gs[n] - o.s[n]) > tol
+            assert bad.mean() <= 0.01, "turning_dir %s: %d of %d differ" % (what, bad.sum(), bad.size)
             continue
         np.testing.assert_allclose(gs[n], o.s[n], rtol=0, atol=tol, err_msg=n + " " + what)
     gobs = g.obs.cpu().numpy().astype(np.float64)

@@ -44,6 +44,7 @@ def inject(o, ep, t):
     o.s["last_action"][:, 1] = ep.col(t, "act1")
     o.s["flags"][:] = ep.flags[t]
     o.s["step_num"][:] = ep.col(t, "step_num").astype(np.int32)
+    o.s["turning_dir"][:] = ep.turning[t]
 
 
 def check_step(o, ep, t, tol):
@@ -51,6 +52,8 @@ def check_step(o, ep, t, tol):
     for n in ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "time_remaining", "t"):
         np.testing.assert_allclose(o.s[n], ep.col(t + 1, n), rtol=0, atol=tol, err_msg="%s @%d" % (n, t))
     assert np.array_equal(o.s["flags"] & MASK, ep.flags[t + 1] & MASK), "flags @%d" % t
+    # Agent.turning_dir (the CADRL network's turning memory: a sign test on the new heading, UnicycleDynamics.py:41-47)
+    np.testing.assert_allclose(o.s["turning_dir"], ep.turning[t + 1], rtol=0, atol=tol, err_msg="turning_dir @%d" % t)
     assert np.array_equal(o.done[0], ep.done[t]), "done @%d" % t
     assert bool(o.game_over[0]) == bool(ep.game_over[t]), "game_over @%d" % t
     assert np.array_equal(o.obs[0][:, 1], ep.obs[t + 1][:, 1]), "num_other_agents @%d" % t
