@@ -11,8 +11,11 @@ the only collective is one RCCL all-reduce of the 8 episode counters.
 The default workload is the metric's; `ga3c20` (BASELINE config 3: 4096 x 20 GA3C-CADRL agents, network on the fp32
 matrix cores) and `crowd50_laser` (config 5: 4096 x 50 RVO agents + static map + LaserScanSensor) are the "next" rows,
 measured with the same harness and reported with their own roofline (profiles/).
-N>1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-Rank 0 prints ONE JSON line.
+N>1: either the driver's launcher form  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+or plain  python bench.py --gpus N  (no WORLD_SIZE in the environment): bench.py then starts the N ranks itself with that
+same launcher.  Either way one rank per GPU; the line is refused unless exactly N ranks took part.  Rank 0 prints ONE
+JSON line.  The timed block of EXACTLY K steps is repeated until >= 0.5 s of device time has been measured and the
+MEDIAN block is reported (`timed_blocks` carries first / min / max).
 """
 import argparse
 import json
@@ -34,7 +37,7 @@ GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
 def measured_traffic_bytes(envs, agents):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, profiles/), if they were
     taken at this geometry; bench.py itself does not run the profiler."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         f = os.path.join(REPO, "profiles", name)
         if os.path.exists(f):
             d = json.load(open(f))
@@ -73,7 +76,7 @@ def cpu_baseline(n_agents, K, budget_s=8.0):
         (independent processes, rates summed -- envs never interact);
       * the reference's OWN Python env.step cannot run here (/root/reference is not on the GPU box): its rate measured in
         the build container by oracle/time_reference.py (1 process and nproc processes, host stated) is attached from
-        profiles/r02_reference_cpu.json."""
+        the newest profiles/r*_reference_cpu.json (re-timed live where the reference is present)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     s1, d1 = _port_leg((n_agents, K, budget_s, 0))
@@ -89,14 +92,36 @@ def cpu_baseline(n_agents, K, budget_s=8.0):
            "host_logical_cores": cores, "single_core_value": s1 / d1,
            "sample": "C++ oracle (oracle/ca_oracle.cpp), 64 envs x %d agents per process, fixture cases with auto-reset: "
                      "1 process for %.1f s (%d agent-steps), then %d processes x ~%.0f s" % (n_agents, d1, s1, procs, budget_s)}
-    ref = os.path.join(REPO, "profiles", "r02_reference_cpu.json")
-    if os.path.exists(ref):
-        r = json.load(open(ref))
-        out["reference_python"] = {"kind": "reference", "measured_where": "build container (the reference does not travel to the GPU box)",
-                                   "host": r["host"], "one_process": r["one_process"]["agent_steps_per_s"],
-                                   "all_cores": r["all_cores"]["agent_steps_per_s"], "cores": r["all_cores"]["cores"],
-                                   "script": "oracle/time_reference.py"}
+    out["reference_python"] = reference_python_rate()
     return out
+
+
+def reference_python_rate():
+    """The reference's own Python env.step.  Where /root/reference exists (the build container) it is RE-TIMED now by
+    oracle/time_reference.py (bounded: ~5 s on one core + ~5 s on all cores); on the GPU box, where the reference cannot
+    travel, the newest committed record profiles/r*_reference_cpu.json (written by the same script) is attached."""
+    import glob
+    import subprocess
+    live = None
+    if os.path.isdir(os.environ.get("CA_REFERENCE_ROOT", "/root/reference")):
+        try:
+            tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cagpu_reference_cpu_%d.json" % os.getpid())
+            subprocess.run([sys.executable, os.path.join(REPO, "oracle", "time_reference.py"), "--seconds", "5", "--out", tmp],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            live = json.load(open(tmp))
+            os.remove(tmp)
+        except Exception as e:  # noqa: BLE001 -- the baseline must never take the bench line down
+            sys.stderr.write("reference re-timing failed: %r\n" % (e,))
+    recs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_reference_cpu.json")))
+    if live is None and not recs:
+        return None
+    r = live if live is not None else json.load(open(recs[-1]))
+    return {"kind": "reference",
+            "measured_where": "this host, in this run" if live is not None else
+                              "build container (the reference does not travel to the GPU box); record profiles/%s" % os.path.basename(recs[-1]),
+            "host": r["host"], "one_process": r["one_process"]["agent_steps_per_s"],
+            "all_cores": r["all_cores"]["agent_steps_per_s"], "cores": r["all_cores"]["cores"],
+            "script": "oracle/time_reference.py"}
 
 
 def env_api_rates(E, N, steps, torch, dev):
@@ -181,6 +206,78 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
                            "algorithmic_bytes_per_agent_step": 104 + 28 * K + 3 * 512 * 4}
 
 
+def build_workload(workload, E, dev, rank=0, world=1, pipeline=True, agents=None):
+    """The simulator of a bench workload, exactly as the timed run uses it (tests/test_gpu_bench_geometry.py builds its
+    full-size parity cases through this function, so the geometry the oracle checks IS the one the bench line reports).
+    -> (sim, fixture table, N, K)"""
+    from gym_collision_avoidance_amd import _native as nat
+    from gym_collision_avoidance_amd import core
+    from gym_collision_avoidance_amd.sharding import shard_env_ids
+    N = agents if agents else {"rvo10": 10, "ga3c20": 20, "crowd50_laser": 50}[workload]
+    K = 19 if workload == "ga3c20" else N - 1
+    table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
+    sort = nat.SORT_CLOSEST_LAST if workload == "ga3c20" else nat.SORT_CLOSEST_FIRST
+    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort), device=dev, pipeline=pipeline)
+    sim.set_plugins(nat.POL_GA3C_CADRL if workload == "ga3c20" else nat.POL_RVO, nat.DYN_UNICYCLE)
+    if workload == "ga3c20":
+        sim.load_ga3c()
+    if workload == "crowd50_laser":  # Map(16 m, 16 m, 0.1 m) with a few wall segments + the 512-beam scan
+        sim.set_map(crowd_map())
+    off, stride = shard_env_ids(rank, world, E)
+    sim.set_fixture_table(table, env_id_offset=off, case_stride=stride)
+    sim.reset_from_table()
+    return sim, table, N, K
+
+
+def crowd_map():
+    grid = np.zeros((160, 160), dtype=bool)
+    grid[40:44, 30:130] = True
+    grid[116:120, 30:130] = True
+    grid[60:100, 78:82] = True
+    return grid
+
+
+def valu_block(E, N, kern_s):
+    """The VALU-issue view of the same launch (the kernel's own analysis says issue-bound): VALU
+    instructions per launch from the committed rocprofv3 PMC pass (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; profiles/) over
+    this run's launch duration, against the device's peak issue rate: 256 CUs x 4 SIMDs x 1 wave-instruction per cycle at
+    2.4 GHz."""
+    for name in ("r04_valu.json", "r03_valu.json"):
+        f = os.path.join(REPO, "profiles", name)
+        if not os.path.exists(f):
+            continue
+        d = json.load(open(f))
+        if d.get("envs") != E or d.get("agents") != N:
+            continue
+        peak = 256 * 4 * 2.4e9
+        out = {"valu_insts_per_launch": d["valu_insts_per_launch"], "valu_insts_per_agent_step": d["valu_insts_per_launch"] / (E * N),
+               "achieved_insts_per_s": d["valu_insts_per_launch"] / kern_s, "peak_insts_per_s": peak,
+               "frac": d["valu_insts_per_launch"] / kern_s / peak, "source": "profiles/" + name,
+               "note": "wave-level VALU instructions; float64 ones issue over two (transcendental: four+) cycles, so the issue "
+                       "pipes are busier than frac says -- valu_busy_frac is the counter that measures that"}
+        if d.get("valu_busy_cycles_per_simd"):
+            out["valu_busy_frac"] = d["valu_busy_cycles_per_simd"] / (kern_s * 2.4e9)
+        return out
+    return None
+
+
+def respawn(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, exactly the
+    command the driver's launcher form uses) and hand their exit code on; rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["CAGPU_BENCH_SPAWNED"] = "1"
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +295,10 @@ def main():
                     help="A/B: without CaState.next_action, i.e. the unpipelined step kernel (policy query at the start of the step)")
     ap.add_argument("--min-warm-seconds", type=float, default=0.3,
                     help="untimed steady-state warm-up on top of --warmup (launches until this much time has passed)")
+    ap.add_argument("--min-timed-seconds", type=float, default=0.5,
+                    help="the timed block of EXACTLY --steps steps is repeated until this much device time has been measured "
+                         "(at most --max-blocks blocks); the line reports the MEDIAN block.  0: a single block")
+    ap.add_argument("--max-blocks", type=int, default=1000)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the rollout / two-stream extras (profiling runs: only the headline kernel is launched)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI)")
@@ -205,12 +306,21 @@ def main():
                     help="testing only: every rank uses cuda:0 (lets a 1-GPU box exercise the N>1 code path with gloo)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(a)   # does not return
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a line whose n_gpus "
+                 "is not the number of ranks that ran" % (a.gpus, world))
+    if world > 1 and not a.share_device and torch.cuda.device_count() < world:
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible (one rank per GPU; --share-device is for 1-GPU tests)"
+                 % (world, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -229,23 +339,8 @@ def main():
     from gym_collision_avoidance_amd.sharding import shard_env_ids, reduce_episode_stats
 
     E = a.envs
-    N = a.agents if a.agents else {"rvo10": 10, "ga3c20": 20, "crowd50_laser": 50}[a.workload]
-    K = 19 if a.workload == "ga3c20" else N - 1
-    table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % N]
-    sort = nat.SORT_CLOSEST_LAST if a.workload == "ga3c20" else nat.SORT_CLOSEST_FIRST
-    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort), device=dev, pipeline=not a.no_pipeline)
-    sim.set_plugins(nat.POL_GA3C_CADRL if a.workload == "ga3c20" else nat.POL_RVO, nat.DYN_UNICYCLE)
-    if a.workload == "ga3c20":
-        sim.load_ga3c()
-    if a.workload == "crowd50_laser":  # Map(16 m, 16 m, 0.1 m) with a few wall segments + the 512-beam scan
-        grid = np.zeros((160, 160), dtype=bool)
-        grid[40:44, 30:130] = True
-        grid[116:120, 30:130] = True
-        grid[60:100, 78:82] = True
-        sim.set_map(grid)
+    sim, table, N, K = build_workload(a.workload, E, dev, rank, world, pipeline=not a.no_pipeline, agents=a.agents)
     off, stride = shard_env_ids(rank, world, E)
-    sim.set_fixture_table(table, env_id_offset=off, case_stride=stride)
-    sim.reset_from_table()
 
     graph = {}
 
@@ -288,37 +383,60 @@ def main():
     while time.perf_counter() - t_w < a.min_warm_seconds:
         run(50 if a.mode in ("step", "graph") else a.steps)
         torch.cuda.synchronize(dev)
-    # ---- timed: EXACTLY a.steps steps between barrier + synchronize on both sides; nothing else inside
-    if world > 1:
-        dist.barrier()
-        run(20 if a.mode == "step" else (50 if a.mode == "graph" else a.steps))   # the barrier idled the device: bring it back before the clock starts
-    torch.cuda.synchronize(dev)
-    ev0.record()            # same stream the kernels are launched on (torch's current stream)
-    t0 = time.perf_counter()
-    run(a.steps)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+
+    # ---- timed: a BLOCK is EXACTLY a.steps steps between barrier + synchronize on both sides, nothing else inside.  One
+    # block of the driver's 20 steps is 0.3 ms of device time -- one preempted launch moves it by 5 %, and a utilisation
+    # sampler never sees it -- so the block is repeated back to back until --min-timed-seconds of device time have been
+    # measured and the line reports the MEDIAN block (per block: max over ranks); first / min / max are reported beside it.
+    def timed_block():
+        if world > 1:
+            dist.barrier()
+            run(20 if a.mode == "step" else (50 if a.mode == "graph" else a.steps))   # the barrier idled the device: bring it back before the clock starts
+        torch.cuda.synchronize(dev)
+        ev0.record()            # same stream the kernels are launched on (torch's current stream)
+        t0 = time.perf_counter()
+        run(a.steps)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+    blocks = [timed_block()]
+    n_blocks = 1
+    if a.min_timed_seconds > 0:
+        n_blocks = int(min(max(1, a.max_blocks if world == 1 else min(a.max_blocks, 200)),
+                           max(1, np.ceil(a.min_timed_seconds / max(blocks[0][1] * 1e-3, 1e-6)))))
+    if world > 1:   # every rank must run the same number of blocks (there is a barrier in each)
+        nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
+        dist.broadcast(nb, 0)
+        n_blocks = int(nb.item())
+    for _ in range(n_blocks - 1):
+        blocks.append(timed_block())
     gc.enable()
     if world > 1:
         dist.barrier()
-    gpu_ms = ev0.elapsed_time(ev1)
-    gpu_ms_local = gpu_ms
+    bt = torch.tensor(blocks, dtype=torch.float64, device=dev)      # [blocks, (wall s, events ms)]
+    bt_local = bt.clone()
     if world > 1:
-        tmax = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, gpu_ms = float(tmax[0].item()), float(tmax[1].item())
+        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+    walls, gpus = bt[:, 0].cpu().numpy(), bt[:, 1].cpu().numpy()
+    mid = int(np.argsort(walls)[len(walls) // 2])                    # the median block (by wall clock)
+    wall, gpu_ms = float(walls[mid]), float(gpus[mid])
+    gpu_ms_local = float(bt_local[mid, 1].item())
     stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective (8 counters), outside the clock
     torch.cuda.synchronize(dev)
     kernel_name = nat.lib().cagpu_last_kernel().decode()
     # ---- multi-GPU evidence the driver can read from the JSON line: ranks seen, per-rank device time of the SAME K
     # steps, and the latency of the one collective (the 8-counter all-reduce), measured outside the step clock
     per_rank_ms, allreduce_us = [gpu_ms_local / a.steps], None
+    ranks_seen = 1
     if world > 1:
         mine = torch.tensor([gpu_ms_local / a.steps], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [float(x.item()) for x in every]
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)                # counts the ranks that actually took part
+        ranks_seen = int(round(float(one.item())))
         probe = sim.episode_stats()
         for _ in range(5):
             reduce_episode_stats(probe, world)
@@ -329,6 +447,8 @@ def main():
             reduce_episode_stats(probe, world)
         torch.cuda.synchronize(dev)
         allreduce_us = (time.perf_counter() - t_c) / 50 * 1e6
+        if ranks_seen != a.gpus:
+            sys.exit("bench.py: %d ranks took part, --gpus %d asked for" % (ranks_seen, a.gpus))
 
     if rank == 0:
         agent_steps = float(world) * E * N * a.steps
@@ -341,6 +461,10 @@ def main():
             "metric": "agent-steps/sec at 4096 envs x 10 agents (RVO)", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
             "event_ms_per_step": gpu_ms / a.steps,   # HIP events around the same K steps (device time only)
+            "timed_blocks": {"blocks": len(walls), "steps_per_block": a.steps, "reported": "median block by wall clock",
+                             "ms_per_step_first": float(walls[0]) * 1e3 / a.steps, "ms_per_step_min": float(walls.min()) * 1e3 / a.steps,
+                             "ms_per_step_max": float(walls.max()) * 1e3 / a.steps,
+                             "device_seconds_timed": float(gpus.sum()) * 1e-3},
             "suspect": bool(abs(wall * 1e3 - gpu_ms) > 0.2 * gpu_ms),  # host wall clock and device time disagree by > 20 %
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]-shaped at the metric size: %d envs/GPU x %d agents, RVOPolicy(ORCA) + "
@@ -354,9 +478,10 @@ def main():
                                          "not re-measured in this run)" % measured_traffic_bytes(E, N)[1],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": kernel_name, "avg_launch_us": kern_s * 1e6,
-                         "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K)},
+                         "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K),
+                         "valu": valu_block(E, N, kern_s) if (a.mode == "step" and a.workload == "rvo10") else None},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
-            "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+            "ranks_seen": ranks_seen,
             "per_rank_event_ms_per_step": per_rank_ms,
             "stats_allreduce_us": allreduce_us,   # the ONLY collective (RCCL all-reduce of 8 float64 counters), off the step path
         }

@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 7   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 8   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -72,7 +72,7 @@ class CaNet(C.Structure):
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults")
 
 _lib = None
 
@@ -110,6 +110,8 @@ def lib():
     L.cagpu_generate_cases.argtypes = [C.c_int64, C.c_int32] + [C.c_double] * 6 + [C.c_uint64, _P, _P, _P]
     L.cagpu_generate_cases_ragged.argtypes = ([C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32] + [C.c_double] * 4 +
                                               [C.c_uint64, _P, _P, _P, _P])
+    L.cagpu_device_faults.argtypes = [_P, C.c_int32]
+    L.cagpu_debug_libm.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
         if n not in ("cagpu_last_error", "cagpu_last_kernel"):
@@ -118,6 +120,24 @@ def lib():
     L.cagpu_last_kernel.restype = C.c_char_p
     _lib = L
     return L
+
+
+def device_faults(clear=True):
+    """cagpu_device_faults: the current device's fault word (0 in normal operation); synchronises the device."""
+    v = C.c_uint32(0)
+    check(lib().cagpu_device_faults(C.byref(v), 1 if clear else 0))
+    return int(v.value)
+
+
+def debug_libm(op, a, b=None):
+    """cagpu_debug_libm on numpy float64 arrays -> (out0, out1): the device's own atan2 / heading sincos / lean divide and
+    square root (parity hook, see include/cagpu.h)."""
+    import numpy as np
+    a = np.ascontiguousarray(a, np.float64).reshape(-1)
+    b = None if b is None else np.ascontiguousarray(b, np.float64).reshape(-1)
+    o0, o1 = np.empty_like(a), np.empty_like(a)
+    check(lib().cagpu_debug_libm(op, a.size, a.ctypes.data, None if b is None else b.ctypes.data, o0.ctypes.data, o1.ctypes.data))
+    return o0, o1
 
 
 def check(rc):

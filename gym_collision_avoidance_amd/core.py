@@ -120,6 +120,25 @@ class BatchedSim(object):
             t = t.to(self.device)
         return t.contiguous()
 
+    def update_params(self, **changes):
+        """Change CaParams fields (e.g. rvo_collab_coeff=0.3) on a live sim.  A pipelined plan -- CaState.next_action of
+        every env and the fixture table's reset_plan / reset_obs -- was computed under the parameters in force when it
+        was made (RVO horizon / collaboration / dt, sensing horizon, neighbour count, the observation layout), so it is
+        forgotten here and the table's reset rows are recomputed.  Writing `sim.p.<field>` directly skips this: call
+        update_params() (or invalidate_plan() + set_fixture_table()) instead."""
+        for k_, v in changes.items():
+            if k_ in ("num_envs", "num_agents", "max_obs"):
+                raise ValueError("%s is fixed at construction (tensor shapes)" % k_)
+            if not hasattr(self.p, k_):
+                raise AttributeError("CaParams has no field %r" % k_)
+            setattr(self.p, k_, v)
+        self._fast_args = None
+        self.invalidate_plan()
+        if self._table is not None:
+            ar = self._ar
+            self.set_fixture_table(self._table, env_id_offset=ar.env_id_offset, case_stride=ar.case_stride,
+                                   heading_seed=ar.heading_seed)
+
     def invalidate_plan(self):
         """Forget the pipelined policy query (CaState.next_action): call after writing state tensors directly."""
         self.state["flags"].bitwise_and_(~nat.PLAN_VALID)
@@ -254,6 +273,8 @@ class BatchedSim(object):
 
     # ---------------------------------------------------------------- the C-ABI calls
     def reset(self, cases, headings=None, mask=None):
+        if self.fresh_outputs:   # the tensors the last step() handed out belong to their holder: never written again
+            self._new_outputs(keep=mask is not None)
         c = self._dev(cases, torch.float64)
         assert tuple(c.shape) == (self.E, self.N, 6), c.shape
         h = self._dev(headings, torch.float64)
@@ -304,12 +325,14 @@ class BatchedSim(object):
                                            C.byref(self._scan), self._stream()))
         return self.scan
 
-    def _new_outputs(self):
+    def _new_outputs(self, keep=False):
+        """keep: the new tensors start as copies of the current ones (a masked reset rewrites only some envs' rows)"""
         co = self._co
-        self.obs = torch.empty_like(self.obs); co.obs = self.obs.data_ptr()
-        self.rewards = torch.empty_like(self.rewards); co.rewards = self.rewards.data_ptr()
-        self.done = torch.empty_like(self.done); co.done = self.done.data_ptr()
-        self.game_over = torch.empty_like(self.game_over); co.game_over = self.game_over.data_ptr()
+        new = (lambda t: t.clone()) if keep else torch.empty_like
+        self.obs = new(self.obs); co.obs = self.obs.data_ptr()
+        self.rewards = new(self.rewards); co.rewards = self.rewards.data_ptr()
+        self.done = new(self.done); co.done = self.done.data_ptr()
+        self.game_over = new(self.game_over); co.game_over = self.game_over.data_ptr()
 
     def step(self, ext_actions=None):
         if ext_actions is None and not self._has_ga3c:
@@ -379,12 +402,26 @@ class BatchedSim(object):
         return True
 
     def observe(self):
+        if self.fresh_outputs:   # (cagpu_observe rewrites obs only: the other outputs carry over)
+            self._new_outputs(keep=True)
         nat.check(self.lib.cagpu_observe(C.byref(self.p), C.byref(self._cs), C.byref(self._co), self._stream()))
         return self.obs
 
     # ---------------------------------------------------------------- statistics
-    def episode_stats(self):
-        """Per-shard episode counters: float64 [8] (see STAT_NAMES), reduced on the device."""
+    def check_faults(self):
+        """Raise if a step kernel flagged a fault on this device since the last check (cagpu_device_faults: a bounded
+        hand-over poll of the pipelined kernel ran out -- the state may be wrong).  Synchronises the device."""
+        with torch.cuda.device(self.device):
+            f = nat.device_faults(clear=True)
+        if f:
+            raise nat.CagpuError("device fault word 0x%x: a hand-over inside the pipelined step kernel timed out; the "
+                                 "simulator state is not to be trusted" % f)
+
+    def episode_stats(self, check=True):
+        """Per-shard episode counters: float64 [8] (see STAT_NAMES), reduced on the device.  A reporting point: the
+        device's fault word is checked here (one small synchronising read)."""
+        if check:
+            self.check_faults()
         return self.state["env_stats"].sum(dim=0)
 
 

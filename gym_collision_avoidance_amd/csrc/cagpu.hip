@@ -1851,9 +1851,28 @@ int launch_pipe1(const KArgs& k, hipStream_t st) {
   return launch_pipe2<NC, TE, false>(k, st);
 }
 
+#ifndef CAGPU_PIPE_TE_MIN
+#define CAGPU_PIPE_TE_MIN 1   // (A/B builds: -DCAGPU_PIPE_TE_MIN=4 is round 3's fixed 4-env tile)
+#endif
 int launch_pipe(const KArgs& k, hipStream_t st) {
   switch (k.p.num_agents) {
-    case 10: return launch_pipe1<10, 4>(k, st);   // (4-env tiles: 1024 workgroups at the metric's 4096 envs, 4 per CU)
+    case 10: {
+      // Tile size by batch size: the largest grid that is still ONE round of resident workgroups (4 per CU).  A launch is
+      // its launch floor + its slowest workgroup, and a workgroup's duration is its longest dependent chain: with 4-env
+      // tiles a 1024-env batch (BASELINE configs[1]) is 256 workgroups -- one per CU, three quarters of the issue slots idle,
+      // every tile with second rounds of its pair phases and the linearProgram3 queue of four envs; as 1024 single-env
+      // tiles every pair phase is one round and a queue holds one env's infeasible agents (profiles/r04_kernel_geometry.md).
+      // Same arithmetic whatever the tile: results do not depend on it (test_pipelined_equals_unpipelined_bit_for_bit).
+      const long cap = 4L * device_cus(), e = k.p.num_envs;
+#ifndef CAGPU_FAST
+      if (CAGPU_PIPE_TE_MIN <= 1 && e <= cap) return launch_pipe1<10, 1>(k, st);
+      if (CAGPU_PIPE_TE_MIN <= 2 && e <= 2 * cap) return launch_pipe1<10, 2>(k, st);
+      if (CAGPU_PIPE_TE_MIN <= 3 && e <= 3 * cap) return launch_pipe1<10, 3>(k, st);
+#else
+      (void)cap; (void)e;
+#endif
+      return launch_pipe1<10, 4>(k, st);   // (4-env tiles: 1024 workgroups at the metric's 4096 envs, 4 per CU)
+    }
 #ifndef CAGPU_FAST
     case 8: return launch_pipe1<8, 8>(k, st);
     case 6: return launch_pipe1<6, 10>(k, st);
@@ -1917,6 +1936,30 @@ int launch_orca(const OrcaArgs& k, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
+}
+
+
+// ---------------------------------------------------------------- parity hook: the device's own libm-dependent operations
+// (cagpu_debug_libm).  The step's results differ from a CPU run of the same algorithm only through these: atan2 (ROCm's
+// ocml, vs glibc's on the host), the heading's sin / cos (sincos_heading above, a short-range kernel) and the lean
+// divide / square root sequences (divq / sqrtq / divd / sqrtd above).
+__global__ void debug_libm_kernel(const int n, const int op, const double* a, const double* b, double* o0, double* o1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r0 = 0.0, r1 = 0.0;
+  switch (op) {
+    case 0: r0 = atan2(x, y); break;                                   // atan2(a, b)
+    case 1: sincos_heading(x, r0, r1); break;                          // (sin a, cos a), a in [-pi, pi]
+    case 2: r0 = divq(static_cast<float>(x), static_cast<float>(y)); r1 = static_cast<float>(x) / static_cast<float>(y); break;
+    case 3: r0 = sqrtq(static_cast<float>(x)); r1 = sqrtf(static_cast<float>(x)); break;
+    case 4: r0 = divd(x, y); r1 = x / y; break;
+    case 5: r0 = sqrtd(x); r1 = sqrt(x); break;
+    case 6: { const Ego e = ego_frame(0.0, 0.0, x, y, 0.0); r0 = e.heading_ego; r1 = e.dist; } break;  // goal (a, b) seen from the origin
+    default: break;
+  }
+  o0[i] = r0;
+  if (o1) o1[i] = r1;
 }
 
 }  // namespace
@@ -2027,6 +2070,10 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   k.rows = net->rows_scratch;
   if (k.rows) {
     if (k.B >= (1L << 31)) return fail(CA_EUNSUPPORTED, "cagpu_ga3c: more than 2^31 agents with rows_scratch%s");
+    // the packing's two counters (slots reserved so far, workgroups arrived) start from zero whatever an aborted earlier
+    // launch or a caller's uninitialised scratch left there; rows_scratch must hold num_envs * num_agents + 3 words
+    if (hipMemsetAsync(net->rows_scratch + k.B + 1, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess)
+      return fail(CA_ELAUNCH, "cagpu_ga3c: clearing the counters of rows_scratch failed (it must hold num_envs * num_agents + 3 int32 words)%s");
     hipLaunchKernelGGL(ga3c::compact_kernel, dim3(static_cast<unsigned>((k.B + 4 * ga3c::CP_NT - 1) / (4 * ga3c::CP_NT))),
                        dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch);
   }
@@ -2177,6 +2224,38 @@ int cagpu_debug_prof(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+
+int cagpu_device_faults(uint32_t* faults, int32_t clear) {
+  if (!faults) return fail(CA_EINVAL, "cagpu_device_faults: NULL pointer%s");
+  unsigned int v = 0u;
+  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(pipe::g_fault), sizeof(v));  // (synchronises the device)
+  if (e == hipSuccess && clear && v) {
+    const unsigned int z = 0u;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pipe::g_fault), &z, sizeof(z));
+  }
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_device_faults: %s", hipGetErrorString(e));
+  *faults = v;
+  return CA_OK;
+}
+
+int cagpu_debug_libm(int32_t op, int32_t n, const double* a, const double* b, double* out0, double* out1) {
+  if (n < 1 || !a || !out0 || op < 0 || op > 6) return fail(CA_EINVAL, "cagpu_debug_libm: bad arguments%s");
+  double* d = nullptr;
+  const size_t sz = sizeof(double) * static_cast<size_t>(n);
+  if (hipMalloc(reinterpret_cast<void**>(&d), 4 * sz) != hipSuccess) return fail(CA_ELAUNCH, "cagpu_debug_libm: hipMalloc failed%s");
+  hipError_t e = hipMemcpy(d, a, sz, hipMemcpyHostToDevice);
+  if (e == hipSuccess && b) e = hipMemcpy(d + n, b, sz, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(debug_libm_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, op, d, b ? d + n : nullptr, d + 2 * n,
+                       d + 3 * n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out0, d + 2 * n, sz, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && out1) e = hipMemcpy(out1, d + 3 * n, sz, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_debug_libm: %s", hipGetErrorString(e));
+  return CA_OK;
+}
 
 int cagpu_orca(int32_t num_envs, int32_t num_agents, const float* pos, const float* vel, const float* pref,
                const float* radius, const float* max_speed, float collab_coeff, float time_horizon, float time_step,

@@ -9,9 +9,10 @@ import numpy as np
 
 
 def load_map_image(map_filename, dims):
-    """Map.py:17-22 without scipy.misc.imresize (removed from SciPy): the image as 8-bit grey levels, imresize's
-    bytescale (min .. max stretched to 0 .. 255 when the image has to be resized), nearest-neighbour resize, invert:
-    dark pixels are obstacles."""
+    """Map.py:17-22 without scipy.misc.imresize (removed from SciPy): the image as grey levels, imresize's bytescale
+    (min .. max stretched to 0 .. 255 when the image has to be resized -- for NON-uint8 pixel data only: scipy's bytescale
+    returns uint8 input unchanged, so an 8-bit map whose brightest pixel is below 255 keeps its levels and every pixel
+    != 255 is an obstacle, exactly as in the reference), nearest-neighbour resize, invert: dark pixels are obstacles."""
     img = None
     try:
         from PIL import Image
@@ -25,15 +26,18 @@ def load_map_image(map_filename, dims):
             raise ImportError("reading a map image needs Pillow or imageio (neither is installed); pass the occupancy grid "
                               "itself with Map(..., static_map=<bool array>) / env.set_static_map(<bool array>)")
         if img.ndim == 3:
-            img = img[..., :3].mean(axis=-1)
+            img = img[..., :3].mean(axis=-1).astype(img.dtype) if img.dtype == np.uint8 else img[..., :3].mean(axis=-1)
         if img.dtype == bool:
             img = img.astype(np.uint8) * 255
     img = np.asarray(img)
     if img.shape != tuple(dims):
         if Image is None:
             raise ImportError("resizing a %s map image to %s needs Pillow" % (img.shape, tuple(dims)))
-        lo, hi = float(img.min()), float(img.max())            # scipy.misc.bytescale, as imresize applied it
-        scaled = np.zeros(img.shape, np.uint8) if hi == lo else np.clip((img - lo) * (255.0 / (hi - lo)) + 0.5, 0, 255).astype(np.uint8)
+        if img.dtype == np.uint8:                               # scipy.misc.bytescale: uint8 data is returned as it is
+            scaled = img
+        else:                                                   # ... anything else is stretched min .. max -> 0 .. 255
+            lo, hi = float(img.min()), float(img.max())
+            scaled = np.zeros(img.shape, np.uint8) if hi == lo else np.clip((img - lo) * (255.0 / (hi - lo)) + 0.5, 0, 255).astype(np.uint8)
         img = np.asarray(Image.fromarray(scaled).resize((dims[1], dims[0]), Image.NEAREST))
     return np.invert(img.astype(np.uint8)).astype(bool)
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 7
+#define CAGPU_VERSION 8
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -200,8 +200,8 @@ typedef struct CaNet {
   const float *fc1_kernel, *fc1_bias;       /* fullyconnected1/{kernel [256,256], bias}                               */
   const float *logits_kernel, *logits_bias; /* logits_p/{kernel [256,11], bias [11]}                                  */
   const float *input_mean, *input_std;      /* graph constants `Const`, `Const_1` [138] (= config.py:93-149)          */
-  /* Scratch for cagpu_ga3c, device int32 [num_envs * num_agents + 3], ZERO-INITIALISED by the caller (the library leaves
-   * its last two words zero after every call), or NULL.  With it the agents that need an action
+  /* Scratch for cagpu_ga3c, device int32 [num_envs * num_agents + 3] (the library clears the two counter words behind the
+   * list at the start of every call; the order of the packed rows across workgroups is unspecified), or NULL.  With it the agents that need an action
    * this step (GA3C-CADRL policy, not done: collision_avoidance_env.py:310-312 queries no others) are packed first and
    * only their rows are evaluated -- in steady state about half of the agents of an evaluation batch are done and wait
    * for their env's game over.  NULL: every 64-agent tile that holds at least one such agent is evaluated whole. */
@@ -292,7 +292,12 @@ int cagpu_rollout(const CaParams *p, const CaState *s, const CaOut *o, const dou
 /* The policy query of the NEXT step ahead of time (collision_avoidance_env.py:305-323 for the built-in RVO policy):
  * fills s->next_action from the CURRENT state and sets CA_PLAN_VALID, without stepping.  cagpu_step / cagpu_rollout keep
  * the plan up to date by themselves; this entry point exists for states that did not come out of a step (the reset state
- * of a fixture table -> CaAutoReset.reset_plan).  Requires s->next_action and num_agents <= 10. */
+ * of a fixture table -> CaAutoReset.reset_plan).  Requires what the pipelined step kernel requires: s->next_action,
+ * num_agents in {2, 3, 4, 5, 6, 8, 10}, closest_first sorting (CA_EUNSUPPORTED otherwise: the step kernels then query the
+ * policy at the start of the step).  A plan is computed under the CaParams of THIS call (rvo_time_horizon,
+ * rvo_collab_coeff, rvo_dt, sensing_horizon, rvo_max_neighbors): whoever changes one of them afterwards must clear
+ * CA_PLAN_VALID in the flag words and recompute CaAutoReset.reset_plan / reset_obs -- the library cannot see that a
+ * parameter differs from the one a stored plan was made with. */
 int cagpu_plan(const CaParams *p, const CaState *s, void *stream);
 
 /* Replaces: rvo2.PyRVOSimulator.doStep() + getAgentVelocity for every agent (call sites
@@ -305,6 +310,22 @@ int cagpu_orca(int32_t num_envs, int32_t num_agents, const float *pos, const flo
 /* Replaces: OtherAgentsStatesSensor.sense + the observation assembly (OtherAgentsStatesSensor.py:58-144,
  * agent.py:323-327) for the CURRENT state, without stepping: rewrites o->obs only. */
 int cagpu_observe(const CaParams *p, const CaState *s, const CaOut *o, void *stream);
+
+/* Device-side fault word of the CURRENT device (synchronises it): bit 0 = a bounded hand-over poll inside the pipelined
+ * step kernel ran out (csrc/cagpu_pipe.inc wait_for), i.e. some launch since the last clear may have produced wrong state.
+ * *faults receives the word; clear != 0 resets it.  0 in normal operation; check it wherever the host synchronises anyway. */
+int cagpu_device_faults(uint32_t *faults, int32_t clear);
+
+/* Parity hook (tests only, synchronous, HOST pointers, default stream): evaluates on the device, element by element, the
+ * operations through which a step's results can differ from a CPU run of the same algorithm -- no reference analogue:
+ *   op 0: out0 = atan2(a, b)            (ROCm's libm; RVOPolicy.py:100, Dynamics.py:36, test_cases.py:554)
+ *   op 1: out0, out1 = sin a, cos a     (the step kernels' short-range kernel for a heading in [-pi, pi]; UnicycleDynamics.py:30-35)
+ *   op 2 / 3: out0 = the lean float divide a / b / square root of a used inside the ORCA phases, out1 = the correctly rounded one
+ *   op 4 / 5: the same for the float64 divide / square root (distances, preferred velocity, ego frame)
+ *   op 6: out0, out1 = heading_ego_frame, dist_to_goal of an agent at the origin with heading 0 and goal (a, b)
+ * tests/test_gpu_bench_geometry.py runs the CPU oracle on ops 0 / 1 to show that they are the ONLY difference (free-running
+ * episodes then agree bit for bit); tests/test_gpu_parity.py pins the operand range in which ops 2 - 5 agree. */
+int cagpu_debug_libm(int32_t op, int32_t n, const double *a, const double *b, double *out0, double *out1);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,20 @@ namespace {
 const double kPi = 3.141592653589793;  // np.pi
 const double kTwoPi = 2.0 * kPi;
 
+// ---- libm hooks (tests only; ca_oracle_set_libm).  The three libm-dependent operations of the step -- atan2 (policy
+// heading RVOPolicy.py:100, ego frame Dynamics.py:36, reset heading test_cases.py:554) and cos / sin of the new heading
+// (UnicycleDynamics.py:30-35) -- go through these pointers, so that a test can run the oracle on ANOTHER libm's results
+// (the GPU's: tests/test_gpu_bench_geometry.py::test_swap_cases_agree_on_the_gpus_libm_bits).  Default: glibc, like numpy.
+typedef double (*Atan2Fn)(double, double);
+typedef void (*SinCosFn)(double, double*, double*);
+Atan2Fn g_atan2 = nullptr;
+SinCosFn g_sincos = nullptr;
+inline double m_atan2(double y, double x) { return g_atan2 ? g_atan2(y, x) : std::atan2(y, x); }
+inline void m_sincos(double a, double& sn, double& cs) {
+  if (g_sincos) g_sincos(a, &sn, &cs);
+  else { cs = std::cos(a); sn = std::sin(a); }
+}
+
 // util.py:141-146
 inline double wrap(double a) {
   while (a >= kPi) a -= kTwoPi;
@@ -66,7 +80,7 @@ inline Ego ego_frame(double px, double py, double gx, double gy, double heading)
   }
   e.orth_x = -e.prll_y;
   e.orth_y = e.prll_x;
-  e.heading_ego = wrap(heading - std::atan2(e.prll_y, e.prll_x));
+  e.heading_ego = wrap(heading - m_atan2(e.prll_y, e.prll_x));
   return e;
 }
 
@@ -216,7 +230,7 @@ void reset_env(const OrcParams& p, const OrcState& s, int e, const double* cs /*
     s.pref_speed[i] = c[4];
     s.radius[i] = c[5];
     s.vel_x[i] = s.vel_y[i] = 0.0;
-    s.heading[i] = hd ? hd[a] : std::atan2(c[3] - c[1], c[2] - c[0]);  // test_cases.py:554-556
+    s.heading[i] = hd ? hd[a] : m_atan2(c[3] - c[1], c[2] - c[0]);  // test_cases.py:554-556
     const double dx = c[0] - c[2], dy = c[1] - c[3];
     s.slt[i] = (std::sqrt(dx * dx + dy * dy) - p.near_goal_threshold) / c[4];  // agent.py:99
     double tr = p.max_time_ratio * s.slt[i];
@@ -302,7 +316,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
         const orca_ref::Vec np_ = orca_ref::advance(body[ia].pos, v, ts);  // :93,:96
         const double dpx = static_cast<double>(np_.x) - s.pos_x[i];       // :97 float32 pos - float64 pos
         const double dpy = static_cast<double>(np_.y) - s.pos_y[i];
-        const double ang = std::atan2(dpy, dpx) - 0.0;                    // :100-101
+        const double ang = m_atan2(dpy, dpx) - 0.0;                    // :100-101
         const double nh = pymod(ang, kTwoPi);                             // :102
         dh = wrap(nh - s.heading[i]);                                     // :103
         spd = (1.0 / p.rvo_dt) * std::sqrt(dpx * dpx + dpy * dpy);        // :106
@@ -369,7 +383,8 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
       } else {
         nh = wrap(a1 + s.heading[i]);  // dynamics/UnicycleDynamics.py:28
       }
-      const double c = std::cos(nh), sn = std::sin(nh);
+      double c, sn;
+      m_sincos(nh, sn, c);
       s.pos_x[i] += a0 * c * p.dt;  // :30-32
       s.pos_y[i] += a0 * sn * p.dt;
       s.vel_x[i] = a0 * c;  // :34-35
@@ -482,7 +497,7 @@ void episode_stats(const OrcParams& p, const OrcState& s, int e) {
 
 extern "C" {
 
-int ca_oracle_version(void) { return 3; }
+int ca_oracle_version(void) { return 4; }
 
 double ca_oracle_round2(double x) { return round2(x); }
 
@@ -503,12 +518,12 @@ int ca_oracle_step(const OrcParams* p, const OrcState* s, const OrcOut* o, const
   return 0;
 }
 
-int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* table, int32_t n_cases,
-                      int64_t env_id_offset, int64_t case_stride, int32_t n_steps) {
+int ca_oracle_rollout_ex(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions, const double* table,
+                         int32_t n_cases, int64_t env_id_offset, int64_t case_stride, int32_t n_steps, const OrcMap* map) {
   const int N = p->num_agents;
   for (int t = 0; t < n_steps; ++t)
     for (int e = 0; e < p->num_envs; ++e) {
-      step_env(*p, *s, *o, nullptr, e);
+      step_env(*p, *s, *o, ext_actions, e, (map && map->static_map) ? map : nullptr);
       if (o->game_over[e]) {  // vec_env.py:120-128: stats, then reset and hand back the reset observation
         episode_stats(*p, *s, e);
         s->reset_count[e] += 1;
@@ -518,6 +533,16 @@ int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, co
       }
     }
   return 0;
+}
+
+int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* table, int32_t n_cases,
+                      int64_t env_id_offset, int64_t case_stride, int32_t n_steps) {
+  return ca_oracle_rollout_ex(p, s, o, nullptr, table, n_cases, env_id_offset, case_stride, n_steps, nullptr);
+}
+
+void ca_oracle_set_libm(double (*atan2_fn)(double, double), void (*sincos_fn)(double, double*, double*)) {
+  g_atan2 = atan2_fn;
+  g_sincos = sincos_fn;
 }
 
 int ca_oracle_step_map(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions, const OrcMap* m) {

@@ -114,6 +114,15 @@ int ca_oracle_step(const OrcParams* p, const OrcState* s, const OrcOut* o, const
 int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* table, int32_t n_cases,
                       int64_t env_id_offset, int64_t case_stride, int32_t n_steps);
 
+/* ca_oracle_rollout with external actions (held constant over the n_steps; NULL = none) and a static map (NULL = none):
+ * the auto-reset loop for the GA3C-CADRL and map workloads (tests at the bench geometries). */
+int ca_oracle_rollout_ex(const OrcParams* p, const OrcState* s, const OrcOut* o, const double* ext_actions, const double* table,
+                         int32_t n_cases, int64_t env_id_offset, int64_t case_stride, int32_t n_steps, const OrcMap* map);
+
+/* Route the step's three libm-dependent operations (atan2; cos / sin of the new heading) through the caller's functions
+ * (NULL = glibc's): lets a test run the oracle on another libm's bits.  Process-wide. */
+void ca_oracle_set_libm(double (*atan2_fn)(double, double), void (*sincos_fn)(double, double*, double*));
+
 /* Stand-alone pieces (same arithmetic as inside step), for per-stage parity tests. */
 /* ORCA: one new velocity per agent from float inputs (rvo2 doStep for every agent of every env). */
 int ca_oracle_orca(int32_t num_envs, int32_t num_agents, const float* pos, const float* vel, const float* pref,

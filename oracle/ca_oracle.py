@@ -217,6 +217,23 @@ class Oracle(object):
                                      C.c_int32(n_steps))
         assert rc == 0
 
+    def rollout_ex(self, table, n_steps, env_id_offset=0, case_stride=None, ext_actions=None):
+        """rollout() with external actions (GA3C-CADRL agents are queried here, once per step, like step()) and this
+        oracle's static map: step + auto-reset for every workload bench.py times."""
+        table = np.ascontiguousarray(table, np.float64)
+        assert table.shape[1:] == (self.N, 6)
+        stride = self.E if case_stride is None else case_stride
+        for _ in range(int(n_steps)):
+            e = ext_actions
+            if (self.s["policy"] == POL_GA3C_CADRL).any():
+                e = self.ga3c_query(e)
+            e = None if e is None else np.ascontiguousarray(e, np.float64)
+            rc = lib().ca_oracle_rollout_ex(C.byref(self.p), C.byref(self.cs), C.byref(self.co),
+                                            None if e is None else _ptr(e, _D), _ptr(table, _D), C.c_int32(table.shape[0]),
+                                            C.c_int64(env_id_offset), C.c_int64(stride), C.c_int32(1),
+                                            None if self.cmap is None else C.byref(self.cmap))
+            assert rc == 0
+
     def view(self, name):
         a = self.s[name]
         return a.reshape(self.E, self.N, *a.shape[1:])
@@ -236,6 +253,27 @@ def orca(pos, vel, pref, radius, max_speed, collab=0.5, time_horizon=5.0, time_s
                               C.c_float(neighbor_dist), _ptr(out, _F))
     assert rc == 0
     return out
+
+
+ATAN2_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double)
+SINCOS_FN = C.CFUNCTYPE(None, C.c_double, _D, _D)
+_libm_keep = []
+
+
+def set_libm(atan2_fn=None, sincos_fn=None):
+    """Route the oracle's atan2 / (sin, cos) through Python callables (None = glibc): atan2_fn(y, x) -> float,
+    sincos_fn(a) -> (sin, cos).  Process-wide; call set_libm() to restore."""
+    a = ATAN2_FN(atan2_fn) if atan2_fn else None
+
+    def _sc(x, ps, pc):
+        sn, cs = sincos_fn(x)
+        ps[0] = sn
+        pc[0] = cs
+    b = SINCOS_FN(_sc) if sincos_fn else None
+    _libm_keep[:] = [a, b]
+    L = lib()
+    L.ca_oracle_set_libm.restype = None
+    L.ca_oracle_set_libm(C.cast(a, C.c_void_p) if a else None, C.cast(b, C.c_void_p) if b else None)
 
 
 def round2(x):

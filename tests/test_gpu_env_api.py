@@ -278,6 +278,30 @@ def test_bench_two_ranks_on_one_gpu():
     assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (the shape of the driver's 1-GPU
+    command): bench.py starts the two ranks itself, the line says n_gpus = ranks_seen = 2 and carries both shards' episodes"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GYM_CONFIG_CLASS", "GYM_CONFIG_PATH")}
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs",
+           "256", "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--min-timed-seconds", "0.02"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_event_ms_per_step"]) == 2
+    assert d["steps"] == 20 and d["timed_blocks"]["steps_per_block"] == 20 and d["timed_blocks"]["blocks"] >= 2
+    assert d["episode_stats"]["episodes"] > 0 and d["value"] > 0
+    # a launcher that started a different number of ranks than --gpus says is refused, not silently reported
+    bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "4", "--steps", "5", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0 and b"refusing" in bad.stderr and not bad.stdout.strip()
+
+
 def test_env_api_laserscan_episode():
     """Config.USE_STATIC_MAP + LaserScanSensor through the reference-shaped API against the reference's record"""
     Config, tc, Env = envtools.fresh("Laser4")

@@ -294,13 +294,21 @@ def test_rollout_equals_repeated_steps(E, T):
 
 
 # ---------------------------------------------------------------- the metric geometry itself (4096 x 10 and its neighbours)
+def _pipe_tile(N, E):
+    """envs per tile of the pipelined kernel on a 256-CU MI355X (launch_pipe, csrc/cagpu.hip): for N = 10 the largest grid
+    that is still one round of resident workgroups (4 per CU), floor(64 / N) for the other agent counts"""
+    if N != 10:
+        return 64 // N
+    return 1 if E <= 1024 else 2 if E <= 2048 else 3 if E <= 3072 else 4
+
+
 def _expected_kernel(E, multi, pipeline=True):
     """the instantiation the launcher must pick on a 256-CU MI355X for N = 10 with precomputed reset observations: the
     software-pipelined kernel (CaState.next_action given) while every workgroup is resident at once; otherwise
     4-env tiles while ceil(E / 4) <= 4 x CUs; the staged observation block only while <= 3 workgroups per CU"""
     wgs4 = (E + 3) // 4
     if pipeline and (wgs4 <= 4 * 256 or wgs4 >= 8 * 256):
-        return "ca_pipe_kernel<10, 4, %s>" % ("true" if multi else "false")
+        return "ca_pipe_kernel<10, %d, %s>" % (_pipe_tile(10, E), "true" if multi else "false")
     te = 4 if wgs4 <= 4 * 256 else 0
     wgs = wgs4 if te == 4 else (E + 5) // 6
     stage = wgs <= 3 * 256
@@ -1016,6 +1024,7 @@ def _assert_same_bits(a, b, what):
 
 
 @pytest.mark.parametrize("N,E,steps,pipeline", [(10, 3073, 12, True), (10, 4096, 12, True), (10, 4096, 12, False),
+                                                (10, 1024, 12, True), (10, 1601, 12, True), (10, 2900, 12, True),
                                                 (10, 5200, 8, True), (10, 8200, 6, True), (20, 300, 12, True), (50, 40, 10, True),
                                                 (4, 333, 12, True), (4, 333, 12, False), (2, 500, 10, True), (3, 211, 10, True),
                                                 (5, 130, 10, True), (6, 97, 10, True), (8, 250, 10, True)])
@@ -1045,7 +1054,7 @@ def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
         g.step()
         kern = nat.lib().cagpu_last_kernel().decode()
         if pipeline and (N in (2, 3, 4, 5, 6, 8) or (N == 10 and (E <= 4096 or E >= 8192))):
-            assert kern.startswith("ca_pipe_kernel<%d, %d, false>" % (N, 4 if N == 10 else 64 // N)), kern
+            assert kern.startswith("ca_pipe_kernel<%d, %d, false>" % (N, _pipe_tile(N, E))), kern
             if t > 0:   # the fast path: every agent that is queried next holds a valid plan
                 assert (g.state["flags"].cpu().numpy().reshape(-1) >> 17 & 1).all()
         else:
@@ -1061,6 +1070,8 @@ def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
 
 
 @pytest.mark.parametrize("E,chunks", [(100, [1] * 40 + [7, 1, 1, 30, 2, 150]), (4096, [1] * 6 + [5, 1, 40, 1, 1]),
+                                      (1024, [1] * 6 + [5, 1, 40, 1, 1]), (2048, [1, 1, 9, 1, 30]), (3001, [1, 1, 9, 1, 30]),
+                                      (6144, [1, 1, 6, 1, 25]),       # single-env, 2-env, 3-env tiles; the 1.5-round grid
                                       (9001, [1, 1, 6, 1, 25])])      # 9001 envs: more workgroups than resident slots
 def test_pipelined_equals_unpipelined_bit_for_bit(E, chunks):
     """CaState.next_action changes WHEN the RVO policy of a step is computed (beside the previous step's sensing half
@@ -1187,3 +1198,60 @@ def test_ragged_batches_vs_oracle_reinjected(N, E, K):
     assert o.s["env_stats"][:, 0].sum() > E // 4
     absent = (o.view("flags") >> 16 & 1).astype(bool)
     assert absent.any() and not g.obs.cpu().numpy()[absent].any() and g.done.cpu().numpy()[absent].all()
+
+
+# ---------------------------------------------------------------- the lean divide / square root sequences (csrc/cagpu.hip divq .. sqrtd)
+def _rand_operands(rng, n, emin, emax):
+    return np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(emin, emax + 1, n)) * rng.choice([-1.0, 1.0], n)
+
+
+def test_lean_divide_and_sqrt_operand_range():
+    """The ORCA phases and the distance / ego-frame code of the step kernels use the compiler's correctly rounded divide and
+    square root sequences WITHOUT their range handling (no v_div_scale / v_div_fixup, no 2^32 rescaling).  Inside the
+    documented operand range they are the IEEE results bit for bit -- that is what lets the step kernel's ORCA be compared
+    bitwise with the oracle -- and this test pins the range: float exponents in [-60, 60] (ORCA's operands are 0 or
+    1e-16 .. 1e8 in magnitude: velocities, positions, their differences and products), float64 exponents in [-300, 300].
+    Beyond it (denormal or overflowing operands / quotients) the lean forms DO diverge: the documented limit of the step
+    kernels (coordinates below 1e8 m), shown here so that it cannot go unnoticed."""
+    nat, core, orc = _mods()
+    rng = np.random.default_rng(42)
+    n = 1 << 20
+    bits = lambda x: np.ascontiguousarray(x).view(np.uint64)
+    f32 = lambda x: x.astype(np.float32).astype(np.float64)
+    # ---- inside the range: identical bits
+    a, b = f32(_rand_operands(rng, n, -60, 60)), f32(_rand_operands(rng, n, -60, 60))
+    lean, ieee = nat.debug_libm(2, a, b)
+    assert np.array_equal(bits(lean), bits(ieee)) and np.array_equal(ieee, f32(a.astype(np.float32) / b.astype(np.float32)))
+    lean, ieee = nat.debug_libm(3, np.abs(f32(_rand_operands(rng, n, -80, 80))))
+    assert np.array_equal(bits(lean), bits(ieee))
+    a, b = _rand_operands(rng, n, -300, 300), _rand_operands(rng, n, -300, 300)
+    lean, ieee = nat.debug_libm(4, a, b)
+    assert np.array_equal(bits(lean), bits(ieee)) and np.array_equal(ieee, a / b)
+    x = np.abs(_rand_operands(rng, n, -600, 600))
+    lean, ieee = nat.debug_libm(5, x)
+    assert np.array_equal(bits(lean), bits(ieee)) and np.array_equal(ieee, np.sqrt(x))
+    # the special operands ORCA does produce: exact zeros
+    z = np.zeros(4)
+    assert np.array_equal(nat.debug_libm(2, z, np.array([1.0, -2.0, 3.5, 1e8]))[0], z)
+    assert np.array_equal(nat.debug_libm(3, z)[0], z) and np.array_equal(nat.debug_libm(5, z)[0], z)
+    # ---- beyond the range: the correctly rounded forms stay IEEE, the lean ones do not
+    report = {}
+    with np.errstate(all="ignore"):
+        for name, op, a, b in (
+                ("float quotient overflows / denormal divisor", 2, f32(_rand_operands(rng, 4096, 60, 120)),
+                 f32(_rand_operands(rng, 4096, -140, -110))),
+                ("float denormal quotient", 2, f32(_rand_operands(rng, 4096, -100, -70)), f32(_rand_operands(rng, 4096, 40, 60))),
+                ("float sqrt of a denormal", 3, np.abs(f32(_rand_operands(rng, 4096, -148, -128))), None),
+                ("float64 quotient overflows", 4, _rand_operands(rng, 4096, 600, 1000), _rand_operands(rng, 4096, -1000, -600)),
+                ("float64 denormal divisor", 4, _rand_operands(rng, 4096, -10, 10), _rand_operands(rng, 4096, -1070, -1030))):
+            lean, ieee = nat.debug_libm(op, a, b)
+            want = {2: lambda: f32(a.astype(np.float32) / b.astype(np.float32)), 3: lambda: f32(np.sqrt(a.astype(np.float32))),
+                    4: lambda: a / b}[op]()
+            same_ieee = (bits(ieee) == bits(want)) | (np.isnan(ieee) & np.isnan(want))
+            report[name] = {"ieee_form_correct": float(same_ieee.mean()),
+                            "lean_equals_ieee": float(((bits(lean) == bits(ieee)) | (np.isnan(lean) & np.isnan(ieee))).mean())}
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        json.dump(report, open(os.path.join(out, "lean_range.json"), "w"), indent=1)
+    assert min(v["lean_equals_ieee"] for v in report.values()) < 1.0, report   # the limit is real: beyond the range they diverge

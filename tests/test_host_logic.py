@@ -338,3 +338,9 @@ def test_map_image_loading(tmp_path):
     f2 = str(tmp_path / "world2.png")
     Image.fromarray(big).save(f2)
     assert np.array_equal(Map(16, 16, 0.1, map_filename=f2).static_map, m.static_map)
+    # an 8-bit map whose brightest level is below 255, resized: scipy's bytescale leaves uint8 data alone, so the
+    # reference's imresize never stretches it and np.invert(...).astype(bool) marks EVERY pixel != 255 as an obstacle
+    dim = np.kron(np.where(img == 255, 200, 0).astype(np.uint8), np.ones((2, 2), dtype=np.uint8))
+    f3 = str(tmp_path / "world3.png")
+    Image.fromarray(dim).save(f3)
+    assert Map(16, 16, 0.1, map_filename=f3).static_map.all()
