@@ -426,7 +426,7 @@ class CollisionAvoidanceEnv(Env):
                     raw = src[e, i] if batched_in else actions[i]
                     ext[e, i] = np.asarray(p.external_action_to_action(agent, raw), dtype=np.float64)
                 elif isinstance(p, InternalPolicy):
-                    ext[e, i] = np.asarray(p.find_next_action(self._obs_dicts(e), group, i), dtype=np.float64)
+                    ext[e, i] = np.asarray(p.find_next_action(self._obs_dicts(e)[i], group, i), dtype=np.float64)   # (:319-323)
         if not batched_in:
             for i, agent in enumerate(self.agents):
                 if i in self._host_policies:

@@ -3,8 +3,9 @@
 Covered: the registries (`policy_dict`, `sensor_dict`, `dynamics_dict`, test_cases.py:68-96), the fixture tables
 (`preset_testCases(n, full_test_suite=True)`, :593-624 -- shipped as data/test_cases.npz, converted from the reference's
 pickles by oracle/gen_golden.py), `cadrl_test_case_to_agents` (:495-590), `full_test_suite` (:593+ plumbing used by
-run_full_test_suite), `get_testcase_two_agents` (:144-175), `gen_circle_test_case` (:900-911) and the hand-written
-small presets, and random scenario generation (`get_testcase_random` -> scenario_generator.py, bit-identical to
+run_full_test_suite), `get_testcase_two_agents` (:144-175), `get_testcase_crazy`, `get_testcase_two_agents_laserscanners`,
+`small_test_suite`, `formation`, `make_testcase_huge`, `yaml_to_agents`, `gen_circle_test_case` (:900-911), the hand-written
+presets (data/presets.npz), and random scenario generation (`get_testcase_random` -> scenario_generator.py, bit-identical to
 gen_rand_testcases.py under the same np.random seed).
 """
 import os
@@ -50,22 +51,36 @@ def fixture_table(num_agents):
     return _tables[num_agents]
 
 
+_presets = None
+
+
 def preset_testCases(num_agents, full_test_suite=False, vpref_constraint=False, radius_bounds=None, carrl=False,
                      seed=None):
-    """list of [N,6] arrays.  full_test_suite=True -> the 500-case fixture; otherwise the small hand-written presets
-    of test_cases.py:626-897 that are plain data (1, 2 and the asymmetric 3/4-agent cases)."""
+    """list of [N,6] arrays.  full_test_suite=True -> the 500-case fixture (test_cases.py:593-624); otherwise the reference's
+    hand-written presets for this agent count (test_cases.py:626-897: 1, 2, 3 / 4, 5, 6, 10 and 20 agents), shipped as
+    data/presets.npz -- recorded from the imported reference by oracle/gen_presets.py, like the fixture tables."""
+    global _presets
     if full_test_suite:
         if vpref_constraint or carrl or seed is not None:
             raise NotImplementedError("only the plain {N}_agents_500_cases fixtures are shipped")
         return list(fixture_table(num_agents))
-    a = np.array
-    if num_agents == 1:
-        return [a([[-3.0, 0.0, 3.0, 0.0, 1.0, 0.3]])]
-    if num_agents == 2:
-        return [a([[-3.0, 0.0, 3.0, 0.0, 1.0, 0.3], [3.0, 0.0, -3.0, 0.0, 1.0, 0.3]]),      # swap
-                a([[-3.0, -1.5, 3.0, 1.5, 1.0, 0.5], [-3.0, 1.5, 3.0, -1.5, 1.0, 0.5]]),    # crossing
-                a([[-2.0, -1.5, 2.0, 1.5, 1.0, 0.5], [-2.0, 1.5, 2.0, -1.5, 0.5, 0.5]])]
-    raise NotImplementedError("hand-written presets for %d agents are not restated; use the fixtures" % num_agents)
+    if _presets is None:
+        with np.load(os.path.join(os.path.dirname(_DATA), "presets.npz")) as z:
+            _presets = {k: z[k] for k in z.files}
+    cases, i = [], 0
+    while "n%d_%d" % (num_agents, i) in _presets:
+        cases.append(_presets["n%d_%d" % (num_agents, i)].copy())
+        i += 1
+    if not cases:  # (the reference prints "invalid num_agents" and fails on the unbound list)
+        raise ValueError("no hand-written presets for %d agents (the reference defines 1, 2, 3, 4, 5, 6, 10, 20)" % num_agents)
+    return cases
+
+
+def small_test_suite(num_agents, test_case_index, policies="learning", agents_dynamics="unicycle",
+                     agents_sensors=("other_agents_states",), vpref_constraint=False, radius_bnds=None):
+    """One of the hand-written presets as Agents (test_cases.py:313-330)."""
+    return cadrl_test_case_to_agents(preset_testCases(num_agents)[test_case_index], policies=policies,
+                                     agents_dynamics=agents_dynamics, agents_sensors=agents_sensors)
 
 
 def gen_circle_test_case(num_agents, radius):
@@ -128,6 +143,86 @@ def get_testcase_two_agents(policies=("learning", "GA3C_CADRL")):
                   [OtherAgentsStatesSensor], 0),
             Agent(g, g, -g, -g, 0.5, 1.0, np.pi, policy_dict[policies[1]], UnicycleDynamics,
                   [OtherAgentsStatesSensor], 1)]
+
+
+def get_testcase_crazy(policy="GA3C_CADRL"):
+    """Three agents in a corridor-like squeeze: the ego (`policy`) drives up the y-axis past two RVO agents, one with it,
+    one against it (test_cases.py:99-141)."""
+    rows = [(0.0, 0.0, 0.0, 8.0, np.pi / 2, policy), (-1.2, 0.0, -1.2, 5.0, np.pi / 2, "RVO"),
+            (-1.2, 2.0, -1.2, -3.0, -np.pi / 2, "RVO")]
+    return [Agent(px, py, gx, gy, 0.8, 1.0, hd, policy_dict[pol], UnicycleDynamics, [OtherAgentsStatesSensor], i)
+            for i, (px, py, gx, gy, hd, pol) in enumerate(rows)]
+
+
+def get_testcase_two_agents_laserscanners(policy="RVO"):
+    """Two agents swapping corners that observe through LaserScanSensor only (test_cases.py:178-209).  The reference
+    hard-codes its legacy PPOPolicy (out of scope here); `policy` names any registered policy."""
+    g = 3
+    return [Agent(-g, -g, g, g, 0.5, 1.0, 0.0, policy_dict[policy], UnicycleDynamics, [LaserScanSensor], 0),
+            Agent(g, g, -g, -g, 0.5, 1.0, np.pi, policy_dict[policy], UnicycleDynamics, [LaserScanSensor], 1)]
+
+
+# goal layouts of formation(): six goals per letter, in units of 2 m (test_cases.py:426-479)
+_FORMATIONS = {
+    "A": [(-1.5, 0.0), (1.5, 0.0), (0.75, 1.5), (-0.75, 1.5), (0.0, 1.5), (0.0, 3.0)],
+    "C": [(0.0, 0.0), (-0.5, 1.0), (-0.5, 2.0), (0.0, 3.0), (1.5, 0.0), (1.5, 3.0)],
+    "L": [(0.0, 0.0), (0.0, 1.0), (0.0, 2.0), (0.0, 3.0), (0.75, 0.0), (1.5, 0.0)],
+    "D": [(0.0, 0.0), (0.0, 1.5), (0.0, 3.0), (1.5, 1.5), (1.2, 2.5), (1.2, 0.5)],
+    "R": [(0.0, 0.0), (0.0, 1.5), (0.0, 3.0), (1.3, 2.8), (1.2, 1.7), (1.7, 0.0)],
+}
+
+
+def formation(agents, letter, num_agents=6):
+    """Send the agents, from where they are, to the points of a letter (A, C, L, D, R) in a random assignment
+    (test_cases.py:425-492): the next env.reset() starts them at their current positions with the new goals."""
+    goals = 2.0 * np.array(_FORMATIONS[letter])
+    order = np.arange(num_agents)
+    np.random.shuffle(order)
+    for agent in agents:
+        px, py = agent.pos_global_frame
+        gx, gy = goals[order[agent.id]]
+        agent.reset(px=px, py=py, gx=gx, gy=gy, heading=agent.heading_global_frame)
+    return agents
+
+
+def make_testcase_huge(num_test_cases=1, num_agents=100, side_length=25, speed_bnds=[0.5, 2.0], radius_bnds=[0.2, 0.8],
+                       policies="GA3C_CADRL"):
+    """[num_test_cases, num_agents, 6] crowd scenarios (test_cases.py:914-976): per agent a speed and a radius, then a start
+    at least 2 m (surface to surface) from every earlier START and a goal at least 2 m from every earlier GOAL and 5 m from
+    its own start, all rejection-sampled from the square [-side_length, side_length]^2.  Same np.random draws, in the
+    same order, as the reference.  (The step kernels hold at most 64 agents per env: INTEGRATION.md.)"""
+    cases = np.empty((num_test_cases, num_agents, 6))
+    for c in cases:
+        for i in range(num_agents):
+            speed = np.random.uniform(speed_bnds[0], speed_bnds[1])
+            radius = np.random.uniform(radius_bnds[0], radius_bnds[1])
+
+            def clearance(x, y, cx, cy):   # smallest surface distance to the points (cx, cy) of the agents placed so far
+                if i == 0:
+                    return np.inf
+                return min(np.linalg.norm(np.array([x - o[cx], y - o[cy]])) - o[5] - radius for o in c[:i])
+            gap = -np.inf
+            while gap < 2.0:
+                px, py = np.random.uniform(-side_length, side_length), np.random.uniform(-side_length, side_length)
+                gap = clearance(px, py, 0, 1)
+            gap, trip = -np.inf, -np.inf
+            while gap < 2.0 or trip < 5.0:
+                gx, gy = np.random.uniform(-side_length, side_length), np.random.uniform(-side_length, side_length)
+                gap = clearance(gx, gy, 2, 3)
+                trip = np.linalg.norm(np.array([px - gx, py - gy]))
+            c[i] = [px, py, gx, gy, speed, radius]
+    return cases
+
+
+def yaml_to_agents(agents_yaml):
+    """[{name: {start_x, start_y, goal_x, goal_y, policy, dynamics}}, ...] -> Agents with radius 0.5, preferred speed 1,
+    heading 0 (test_cases.py:1021-1041)."""
+    agents = []
+    for i, item in enumerate(agents_yaml):
+        d = item[list(item.keys())[0]]
+        agents.append(Agent(d["start_x"], d["start_y"], d["goal_x"], d["goal_y"], 0.5, 1.0, 0.0, policy_dict[d["policy"]],
+                            dynamics_dict[d["dynamics"]], [OtherAgentsStatesSensor], i))
+    return agents
 
 
 def get_testcase_random(num_agents=None, side_length=4, speed_bnds=[0.5, 2.0], radius_bnds=[0.2, 0.8],

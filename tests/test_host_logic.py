@@ -344,3 +344,29 @@ def test_map_image_loading(tmp_path):
     f3 = str(tmp_path / "world3.png")
     Image.fromarray(dim).save(f3)
     assert Map(16, 16, 0.1, map_filename=f3).static_map.all()
+
+
+def test_scenario_builders_match_the_reference():
+    """make_testcase_huge / formation / get_testcase_crazy / the hand-written presets against what the imported reference
+    returned under the same np.random seed (oracle/gen_presets.py -> tests/golden/builders.npz, data/presets.npz)"""
+    os.environ.setdefault("GYM_CONFIG_CLASS", "EvaluateConfig")
+    from gym_collision_avoidance_amd.envs import test_cases as tc
+    g = np.load(os.path.join(REPO, "tests", "golden", "builders.npz"))
+    np.random.seed(3)
+    assert np.array_equal(tc.make_testcase_huge(1, 12, 10), g["huge_seed3_12_10"])
+    np.random.seed(0)
+    agents = tc.cadrl_test_case_to_agents(tc.preset_testCases(6)[0], policies="noncoop")
+    tc.formation(agents, "C")
+    got = np.array([[*a.pos_global_frame, *a.goal_global_frame, a.heading_global_frame] for a in agents])
+    np.testing.assert_allclose(got, g["formation_C_seed0"], rtol=0, atol=1e-12)
+    crazy = tc.get_testcase_crazy("noncoop")
+    got = np.array([[*a.pos_global_frame, *a.goal_global_frame, a.pref_speed, a.radius, a.heading_global_frame] for a in crazy])
+    np.testing.assert_allclose(got, g["crazy"], rtol=0, atol=1e-12)
+    assert [len(tc.preset_testCases(n)) for n in (1, 2, 3, 4, 5, 6, 10, 20)] == [2, 8, 9, 9, 2, 4, 1, 1]
+    assert len(tc.small_test_suite(4, 7, policies="RVO")) == 4
+    with pytest.raises(AssertionError):     # (like the reference's sensor: LaserScanSensor needs Config.USE_STATIC_MAP)
+        tc.get_testcase_two_agents_laserscanners()
+    a = tc.yaml_to_agents([{"robot": dict(start_x=0, start_y=1, goal_x=2, goal_y=3, policy="RVO", dynamics="unicycle")}])
+    assert len(a) == 1 and a[0].radius == 0.5 and a[0].pref_speed == 1.0
+    with pytest.raises(ValueError):
+        tc.preset_testCases(7)
