@@ -349,8 +349,7 @@ def test_map_image_loading(tmp_path):
 def test_scenario_builders_match_the_reference():
     """make_testcase_huge / formation / get_testcase_crazy / the hand-written presets against what the imported reference
     returned under the same np.random seed (oracle/gen_presets.py -> tests/golden/builders.npz, data/presets.npz)"""
-    os.environ.setdefault("GYM_CONFIG_CLASS", "EvaluateConfig")
-    from gym_collision_avoidance_amd.envs import test_cases as tc
+    Config, tc, _ = envtools.fresh("Bench10")    # (an EVALUATE_MODE config, like the one the vectors were recorded under)
     g = np.load(os.path.join(REPO, "tests", "golden", "builders.npz"))
     np.random.seed(3)
     assert np.array_equal(tc.make_testcase_huge(1, 12, 10), g["huge_seed3_12_10"])
