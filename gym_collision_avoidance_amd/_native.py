@@ -35,7 +35,7 @@ class CaParams(C.Structure):
 
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
                 "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
-                "reset_count", "env_stats", "next_action", "turning_dir")
+                "reset_count", "env_stats", "next_action", "turning_dir", "rvo_collab", "rvo_heading_noise")
 OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel")
 
 
@@ -68,7 +68,8 @@ NET_FIELDS = ("lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer
 
 
 class CaNet(C.Structure):
-    _fields_ = [(n, _P) for n in NET_FIELDS] + [("rows_scratch", _P)]
+    _fields_ = [(n, _P) for n in NET_FIELDS] + [("rows_scratch", _P), ("agent_net", _P), ("net_index", C.c_int32),
+                                                ("reserved0", C.c_int32)]
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",

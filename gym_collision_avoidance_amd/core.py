@@ -83,7 +83,8 @@ class BatchedSim(object):
         self.game_over = z((E,), torch.uint8)
         self.actions = z((E, N, 2), torch.float32) if record_actions else None
         self.orca_vel = z((E, N, 2), torch.float32) if record_actions else None
-        self._cs = nat.CaState(**{n: self.state[n].data_ptr() for n in nat.STATE_FIELDS})
+        self._cs = nat.CaState(**{n: self.state[n].data_ptr() for n in nat.STATE_FIELDS if n in self.state})
+        self._rvo = None          # RVOPolicy's stochastic branches (set_rvo_stochastic)
         if not self.pipeline:
             self._cs.next_action = None
         self._co = nat.CaOut(obs=self.obs.data_ptr(), rewards=self.rewards.data_ptr(), done=self.done.data_ptr(),
@@ -102,8 +103,10 @@ class BatchedSim(object):
         self._map = None
         self._scan = None
         self.scan = None
-        self._net = None          # GA3C-CADRL weights (load_ga3c)
+        self._net = None          # GA3C-CADRL weights (load_ga3c); _nets: {checkpoint index: (CaNet, tensors)}
         self._net_tensors = None
+        self._nets = {}
+        self._agent_net = None    # int32 [E, N]: which checkpoint an agent runs (set_ga3c_assignment)
         self._has_ga3c = False    # some agent's policy is CA_POL_GA3C_CADRL (set_plugins)
         self._ga3c_ext = None
         self.ga3c_logits = None
@@ -139,6 +142,51 @@ class BatchedSim(object):
             self.set_fixture_table(self._table, env_id_offset=ar.env_id_offset, case_stride=ar.case_stride,
                                    heading_seed=ar.heading_seed)
 
+    def set_rvo_stochastic(self, heading_noise=None, collab_coeff=None, anti_collab_t=1.0, seed=0, noise_std=0.5):
+        """RVOPolicy's two stochastic branches for a whole batch, drawn on the DEVICE (torch's Philox generator) right
+        before every step launch and handed to the kernel as CaState.rvo_collab / rvo_heading_noise:
+          * heading_noise: bool mask broadcastable to [E, N] -- agents whose policy has `heading_noise` set get
+            N(0, noise_std) added to their delta heading each query (policies/RVOPolicy.py:118-119);
+          * collab_coeff < 0: anti-collaborative agents (RVOPolicy.py:77-88) -- every agent carries the policy object's
+            `use_non_coop_policy` (initially True); whenever its clock is within DT of a multiple of anti_collab_t
+            (`round(t % T, 3) < DT or round(T - t % T, 3) < DT`) it is redrawn, True with probability 1 - |c|; the ego's
+            collaboration coefficient of the query is 0 while it is True, c otherwise.
+        Both None: switched off (the deterministic kernels, pipelined plan included).  The reference draws from numpy's
+        global stream, one agent after the other: the batched draws are the same distributions, not the same numbers."""
+        self._fast_args = None
+        if heading_noise is None and (collab_coeff is None or collab_coeff >= 0):
+            self._rvo = None
+            self._cs.rvo_collab = None
+            self._cs.rvo_heading_noise = None
+            return
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        mask = None
+        if heading_noise is not None:
+            mask = torch.from_numpy(np.array(np.broadcast_to(np.asarray(heading_noise, bool), (self.E, self.N)))).to(self.device)
+        self._rvo = dict(gen=gen, mask=mask, std=float(noise_std), T=float(anti_collab_t),
+                         c=None if (collab_coeff is None or collab_coeff >= 0) else float(collab_coeff),
+                         non_coop=torch.ones((self.E, self.N), dtype=torch.bool, device=self.device),  # RVOPolicy.py:33
+                         collab=None, noise=None)
+        self.invalidate_plan()
+
+    def _rvo_draw(self):
+        """this step's draws (see set_rvo_stochastic): a handful of small device ops, no host synchronisation"""
+        r = self._rvo
+        if r["c"] is not None:
+            t, T, dt = self.state["t"], r["T"], float(self.p.rvo_dt)
+            tm = torch.remainder(t, T)
+            r3 = lambda x: torch.round(x * 1000.0) / 1000.0        # numpy's scalar round(x, 3)
+            redraw = (r3(tm) < dt) | (r3(T - tm) < dt)
+            u = torch.rand((self.E, self.N), generator=r["gen"], device=self.device, dtype=torch.float64)
+            r["non_coop"] = torch.where(redraw, u < (1.0 - abs(r["c"])), r["non_coop"])   # np.random.choice([True, False], p=[1 - |c|, |c|])
+            r["collab"] = torch.where(r["non_coop"], 0.0, r["c"]).to(torch.float32).contiguous()
+            self._cs.rvo_collab = r["collab"].data_ptr()
+        if r["mask"] is not None:
+            z = torch.randn((self.E, self.N), generator=r["gen"], device=self.device, dtype=torch.float64)
+            r["noise"] = (z * r["std"] * r["mask"]).contiguous()
+            self._cs.rvo_heading_noise = r["noise"].data_ptr()
+
     def invalidate_plan(self):
         """Forget the pipelined policy query (CaState.next_action): call after writing state tensors directly."""
         self.state["flags"].bitwise_and_(~nat.PLAN_VALID)
@@ -163,10 +211,13 @@ class BatchedSim(object):
         """number of agents the last ga3c() call evaluated (device -> host read: synchronises)"""
         return int(self._net_tensors["rows_scratch"][self.E * self.N].item())
 
-    def load_ga3c(self, weights=None, keep_logits=False):
+    def load_ga3c(self, weights=None, keep_logits=False, index=0):
         """Upload the GA3C-CADRL network (GA3CCADRLPolicy.initialize_network, GA3CCADRLPolicy.py:23-47).  `weights`:
         an .npz written by oracle/extract_ga3c_weights.py (default: the shipped IROS18/network_01900000, the
-        reference's default checkpoint) or a dict of float32 arrays with the same keys."""
+        reference's default checkpoint) or a dict of float32 arrays with the same keys.
+        `index`: several checkpoints may be loaded side by side (index 0, 1, ...); set_ga3c_assignment() says which agent
+        runs which (the reference gives every agent its own policy object and session).  Without an assignment every
+        GA3C-CADRL agent runs checkpoint 0."""
         if weights is None:
             weights = GA3C_DEFAULT_WEIGHTS
         if isinstance(weights, str):
@@ -184,10 +235,25 @@ class BatchedSim(object):
             ts[f] = torch.from_numpy(a).to(self.device)
         # scratch of cagpu_ga3c: the packed list of the agents that need an action this step (+ their count)
         ts["rows_scratch"] = torch.zeros((self.E * self.N + 3,), dtype=torch.int32, device=self.device)
-        self._net_tensors = ts
-        self._net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch",)})
-        self.ga3c_logits = torch.zeros((self.E, self.N, 11), dtype=torch.float32, device=self.device) \
-            if keep_logits else None
+        net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch",)})
+        self._nets[int(index)] = (net, ts)
+        if int(index) == 0 or self._net is None:
+            self._net_tensors, self._net = ts, net
+        if keep_logits or self.ga3c_logits is None:
+            self.ga3c_logits = torch.zeros((self.E, self.N, 11), dtype=torch.float32, device=self.device) \
+                if keep_logits else None
+
+    def set_ga3c_assignment(self, index):
+        """index: int array broadcastable to [E, N] -- the checkpoint (load_ga3c(..., index=)) each GA3C-CADRL agent runs;
+        None: everybody runs checkpoint 0."""
+        if index is None:
+            self._agent_net = None
+            return
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(index, np.int32), (self.E, self.N)))
+        missing = set(np.unique(a).tolist()) - set(self._nets)
+        if missing:
+            raise nat.CagpuError("GA3C-CADRL checkpoint index %s assigned but not loaded" % sorted(missing))
+        self._agent_net = torch.from_numpy(a).to(self.device)
 
     def ga3c(self, ext=None):
         """Query the network for every live GA3C-CADRL agent on the CURRENT observation; the action indices land in
@@ -199,9 +265,17 @@ class BatchedSim(object):
             if self._ga3c_ext is None:
                 self._ga3c_ext = torch.zeros((self.E, self.N, 2), dtype=torch.float64, device=self.device)
             ext = self._ga3c_ext
-        nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(self._net),
-                                      ext.data_ptr(), None if self.ga3c_logits is None else self.ga3c_logits.data_ptr(),
-                                      self._stream()))
+        lg = None if self.ga3c_logits is None else self.ga3c_logits.data_ptr()
+        if self._agent_net is None:      # one checkpoint (index 0) for every GA3C-CADRL agent
+            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(self._net),
+                                          ext.data_ptr(), lg, self._stream()))
+            return ext
+        for idx in sorted(self._nets):   # one launch per checkpoint, each over its own agents (CaNet.agent_net / net_index)
+            net = self._nets[idx][0]
+            net.agent_net, net.net_index = self._agent_net.data_ptr(), idx
+            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(net),
+                                          ext.data_ptr(), lg, self._stream()))
+            net.agent_net = None
         return ext
 
     def generate_cases(self, num_cases, seed, side_length=4.0, speed_bnds=(0.5, 2.0), radius_bnds=(0.2, 0.8),
@@ -335,6 +409,8 @@ class BatchedSim(object):
         self.game_over = new(self.game_over); co.game_over = self.game_over.data_ptr()
 
     def step(self, ext_actions=None):
+        if self._rvo is not None:
+            self._rvo_draw()
         if ext_actions is None and not self._has_ga3c:
             # env.step(None) with built-in policies only (env_utils.py:50): the per-step host path is one ctypes call
             # with prebuilt arguments -- at ~20 us per launch the interpreter is otherwise on the critical path
@@ -377,7 +453,7 @@ class BatchedSim(object):
         return self.obs, self.rewards, self.game_over
 
     def rollout(self, n_steps, ext_actions=None):
-        if self._has_ga3c:  # the network runs between steps: one inference + one step launch per step
+        if self._has_ga3c or self._rvo is not None:  # the network / the stochastic RVO draws run between steps
             for _ in range(int(n_steps)):
                 self.step(ext_actions)
             return self.obs, self.rewards, self.game_over

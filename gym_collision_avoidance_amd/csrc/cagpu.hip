@@ -843,9 +843,11 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
           if (valid) {
             if (jo == 0) sh_nb[ag] = n;
             if (dj < INFINITY && rank < n) {
+              // (the ego's own collaboration coefficient where the caller drew one per agent: RVOPolicy.py:77-90)
+              const float cf = k.s.rvo_collab ? k.s.rvo_collab[env0 * N + ag] : collab;
               Lmat[rank * CS + ag] = half_plane_sel(mpos, f2(sh_fvx[ag], sh_fvy[ag]), sh_frad[ag],
                                                      f2(sh_fpx[eb + j], sh_fpy[eb + j]), f2(sh_fvx[eb + j], sh_fvy[eb + j]),
-                                                     sh_frad[eb + j], collab, inv_h, inv_dt);
+                                                     sh_frad[eb + j], cf, inv_h, inv_dt);
             }
           }
         }
@@ -1062,6 +1064,7 @@ LP1_UNROLL
               dh = ((dh > 0.0) - (dh < 0.0)) * (kPi / 6);
               spd = 0.0;
             }
+            if (k.s.rvo_heading_noise) dh = dh + k.s.rvo_heading_noise[i];  // RVOPolicy.py:118-119 (drawn by the caller)
           } else if (pol == CA_POL_NONCOOP) {  // NonCooperativePolicy.py:21
             const Ego eg = ego_frame(r.px, r.py, r.gx, r.gy, r.heading);
             spd = r.ps;
@@ -1816,6 +1819,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
 bool pipe_eligible(const KArgs& k) {
   const int n = k.p.num_agents;
   if (!k.s.next_action || k.stage_obs) return false;
+  if (k.s.rvo_collab || k.s.rvo_heading_noise) return false;  // (per-step draws belong to the step that consumes them)
 #ifdef CAGPU_FAST
   if (n != 10) return false;
 #endif
@@ -2062,7 +2066,8 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
     if (hipMemsetAsync(net->rows_scratch + k.B + 1, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess)
       return fail(CA_ELAUNCH, "cagpu_ga3c: clearing the counters of rows_scratch failed (it must hold num_envs * num_agents + 3 int32 words)%s");
     hipLaunchKernelGGL(ga3c::compact_kernel, dim3(static_cast<unsigned>((k.B + 4 * ga3c::CP_NT - 1) / (4 * ga3c::CP_NT))),
-                       dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch);
+                       dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch, net->agent_net,
+                       net->net_index);
   }
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
   static thread_local bool lds_raised[16] = {false};

@@ -248,7 +248,9 @@ class CollisionAvoidanceEnv(Env):
         self._host_policies = []   # (of the agent list this was last called for: _upload ends with env 0's)
         for i, a in enumerate(agents):
             p = a.policy
-            if type(p) in _BUILTIN_POLICIES and not getattr(p, "needs_host", False):
+            # (RVOPolicy's stochastic branches: on the host through find_next_action for a single env -- the reference's own
+            # np.random calls --, in a batch as per-step device draws, core.BatchedSim.set_rvo_stochastic)
+            if type(p) in _BUILTIN_POLICIES and not (getattr(p, "needs_host", False) and self.num_envs == 1):
                 pol.append(p.kernel_id)
             else:  # user plugin: queried on the host, handed to the kernel as a raw command
                 pol.append(nat.POL_EXTERNAL)
@@ -362,16 +364,41 @@ class CollisionAvoidanceEnv(Env):
         if E > 1 and any(g is None for g in (per_env or [])) and self._host_policies:
             raise NotImplementedError("user-defined Python policies in a batch need one agent list per env (their policy "
                                       "objects carry per-agent state): set_agents([[...] for each env])")
+        if E > 1:   # RVOPolicy.py:77-90, :118-119 for the whole batch
+            noise = np.zeros((E, N), dtype=bool)
+            for e_, g_ in enumerate(groups):
+                for a_, agent in enumerate(g_):
+                    if isinstance(agent.policy, RVOPolicy) and agent.policy.heading_noise:
+                        noise[slice(None) if self._fixture is not None else e_, a_] = True
+            self._rvo_seed = getattr(self, "_rvo_seed", 0) + 1
+            sim.set_rvo_stochastic(heading_noise=noise if noise.any() else None, collab_coeff=Config.RVO_COLLAB_COEFF,
+                                   anti_collab_t=Config.RVO_ANTI_COLLAB_T,
+                                   seed=int(np.random.randint(1 << 31)) + self._rvo_seed)
+        else:
+            sim.set_rvo_stochastic()
         nets = [a.policy for g in groups for a in g if isinstance(a.policy, GA3CCADRLPolicy)]
         if nets:  # GA3CCADRLPolicy.initialize_network must have run (the reference has no session otherwise)
             paths = {n.weights_path for n in nets}
             if None in paths:
                 raise RuntimeError("a GA3CCADRLPolicy agent was not initialised: call agent.policy.initialize_network()")
-            if len(paths) > 1:
-                raise NotImplementedError("all GA3C-CADRL agents of a batch must share one checkpoint: %s" % sorted(paths))
-            if getattr(sim, "_net_path", None) != nets[0].weights_path:
-                sim.load_ga3c(nets[0].weights)
-                sim._net_path = nets[0].weights_path
+            order = sorted(paths)
+            if getattr(sim, "_net_paths", None) != order:
+                sim._nets.clear()
+                sim._net = None
+                for idx, path in enumerate(order):
+                    sim.load_ga3c(next(n.weights for n in nets if n.weights_path == path), index=idx)
+                sim._net_paths = order
+            if len(order) > 1:
+                # agents of one batch on different checkpoints (every agent owns its policy object and session in the
+                # reference): one cagpu_ga3c launch per checkpoint over its own agents (CaNet.agent_net / net_index)
+                assign = np.zeros((E, N), dtype=np.int32)
+                for e_, g_ in enumerate(groups):    # (a fixture batch: one agent list describes the slots of every env)
+                    for a_, agent in enumerate(g_):
+                        if isinstance(agent.policy, GA3CCADRLPolicy):
+                            assign[slice(None) if self._fixture is not None else e_, a_] = order.index(agent.policy.weights_path)
+                sim.set_ga3c_assignment(assign)
+            else:
+                sim.set_ga3c_assignment(None)
         for e, g in enumerate(groups if self._fixture is None else [agents0]):
             if per_env is None or per_env[e] is not None or e == 0:
                 for a_idx, agent in enumerate(g):

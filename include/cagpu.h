@@ -134,6 +134,18 @@ typedef struct CaState {
   double *turning_dir;         /* [E*N] or NULL (not maintained).  Agent.turning_dir: the CADRL value network's turning
                                   memory, updated by UnicycleDynamics.step only (UnicycleDynamics.py:41-47), zeroed by
                                   Agent.reset (agent.py:133) */
+  /* Per-step inputs of RVOPolicy's two stochastic branches (policies/RVOPolicy.py:77-90, :118-119), drawn by the CALLER
+   * on the device before the launch (the host mirror does it with torch's device generator: core.BatchedSim
+   * .set_rvo_stochastic) -- both NULL in the deterministic case, i.e. always in the reference's shipped configurations:
+   *   rvo_collab        float  [E*N] or NULL: the collaboration coefficient of each agent AS THE EGO of its query
+   *                     (setAgentCollabCoeff, :86-90) -- Config.RVO_COLLAB_COEFF, or 0 while an anti-collaborative agent
+   *                     (RVO_COLLAB_COEFF < 0) is in its non-cooperative phase; NULL: CaParams.rvo_collab_coeff for all.
+   *   rvo_heading_noise double [E*N] or NULL: added to the delta heading of an RVO agent's action after the pi/6 clip
+   *                     (`delta_heading + np.random.normal(0, 0.5)`, :118-119); 0 for agents without heading_noise.
+   * With either one set the policy is queried at the start of the step (the pipelined plan -- next_action -- is not
+   * used: the draws belong to the step that consumes them). */
+  const float *rvo_collab;
+  const double *rvo_heading_noise;
 } CaState;
 
 /* Device pointers to what a step hands back (collision_avoidance_env.py:225-234). */
@@ -206,6 +218,12 @@ typedef struct CaNet {
    * only their rows are evaluated -- in steady state about half of the agents of an evaluation batch are done and wait
    * for their env's game over.  NULL: every 64-agent tile that holds at least one such agent is evaluated whole. */
   int32_t *rows_scratch;
+  /* Which agents this checkpoint drives (the reference gives every agent its own policy object and network session,
+   * GA3CCADRLPolicy.py:23-47, so agents of one scene may run different checkpoints): device int32 [num_envs * num_agents]
+   * or NULL.  With it, cagpu_ga3c evaluates only the agents with agent_net[i] == net_index; the caller makes one call per
+   * distinct checkpoint (each writes its own agents' entries of ext_actions).  NULL: every live GA3C-CADRL agent. */
+  const int32_t *agent_net;
+  int32_t net_index, reserved0;
 } CaNet;
 
 int cagpu_version(void);

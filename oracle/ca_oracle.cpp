@@ -303,7 +303,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
             body[j].pref = orca_ref::mk(static_cast<float>(sc * vx), static_cast<float>(sc * vy));
             body[j].radius = static_cast<float>((1 + 5e-2) * s.radius[q]);  // :71
             body[j].max_speed = static_cast<float>(s.pref_speed[q]);        // :70
-            body[j].collab = static_cast<float>(p.rvo_collab_coeff);        // :90 (only the ego's is used)
+            body[j].collab = s.rvo_collab ? s.rvo_collab[q] : static_cast<float>(p.rvo_collab_coeff);  // :86-90 (only the ego's is used)
           }
           have_bodies = true;
         }
@@ -324,6 +324,7 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
           dh = sgn(dh) * (kPi / 6);
           spd = 0.0;
         }
+        if (s.rvo_heading_noise) dh = dh + s.rvo_heading_noise[i];        // :118-119 (the caller's draw)
       } break;
       case ORC_POL_NONCOOP: {  // policies/NonCooperativePolicy.py:21
         const Ego eg = ego_frame(s.pos_x[i], s.pos_y[i], s.goal_x[i], s.goal_y[i], s.heading[i]);

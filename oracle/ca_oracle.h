@@ -67,6 +67,9 @@ typedef struct {
   int32_t *episode_step, *reset_count;
   double *env_stats; /* [E,8]: episodes, collision_eps, all_at_goal_eps, stuck_eps, sum steps,
                         sum total_reward, sum time_to_goal, sum extra_time_to_goal (env_utils.py:56-87) */
+  /* per-step inputs of RVOPolicy's stochastic branches, both nullable (RVOPolicy.py:77-90, :118-119; include/cagpu.h) */
+  const float *rvo_collab;          /* [E*N] the collaboration coefficient of each agent as the ego of its query */
+  const double *rvo_heading_noise;  /* [E*N] added to an RVO agent's delta heading after the pi/6 clip */
 } OrcState;
 
 typedef struct {

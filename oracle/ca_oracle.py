@@ -45,7 +45,8 @@ _STATE_F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y",
 class OrcState(C.Structure):
     _fields_ = [(n, _D) for n in _STATE_F64] + [("last_action", _F), ("flags", _U32), ("policy", _I32),
                                                 ("dynamics", _I32), ("step_num", _I32), ("episode_step", _I32),
-                                                ("reset_count", _I32), ("env_stats", _D)]
+                                                ("reset_count", _I32), ("env_stats", _D), ("rvo_collab", _F),
+                                                ("rvo_heading_noise", _D)]
 
 
 class OrcOut(C.Structure):
@@ -137,10 +138,21 @@ class Oracle(object):
     def _bind(self):
         st = OrcState()
         for n, t in OrcState._fields_:
-            setattr(st, n, _ptr(self.s[n], t))
+            if n in self.s:
+                setattr(st, n, _ptr(self.s[n], t))
         self.cs = st
         self.co = OrcOut(_ptr(self.obs, _D), _ptr(self.rewards, _D), _ptr(self.done, _U8), _ptr(self.game_over, _U8),
                          _ptr(self.actions, _F), _ptr(self.orca_vel, _F))
+
+    def set_rvo_stochastic(self, collab=None, heading_noise=None):
+        """this step's draws of RVOPolicy's stochastic branches (RVOPolicy.py:77-90, :118-119): float32 [E*N] ego
+        collaboration coefficients and / or float64 [E*N] heading noise; None switches a branch off"""
+        for name, arr, dt in (("rvo_collab", collab, np.float32), ("rvo_heading_noise", heading_noise, np.float64)):
+            if arr is None:
+                self.s.pop(name, None)
+            else:
+                self.s[name] = np.ascontiguousarray(np.asarray(arr, dt).reshape(-1))
+        self._bind()
 
     def set_policies(self, policy, dynamics=None):
         pol = np.broadcast_to(np.asarray(policy, np.int32).reshape(-1, self.N) if np.ndim(policy) else policy,

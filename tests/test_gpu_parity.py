@@ -1258,3 +1258,97 @@ def test_lean_divide_and_sqrt_operand_range():
     for name in ("float quotient overflows / denormal divisor", "float sqrt of a denormal", "float64 quotient overflows",
                  "float64 denormal divisor"):
         assert report[name]["lean_equals_ieee"] < 0.01, report   # the limit is real: beyond the range they diverge
+
+
+# ---------------------------------------------------------------- RVOPolicy's stochastic branches as per-step inputs
+@pytest.mark.parametrize("N,E", [(10, 300), (4, 100), (20, 60)])
+def test_rvo_stochastic_inputs_vs_oracle(N, E):
+    """CaState.rvo_collab / rvo_heading_noise (RVOPolicy.py:77-90, :118-119: the ego's collaboration coefficient of each
+    query, the noise added to the clipped delta heading): the same draws handed to the kernel and to the oracle give the
+    same ORCA velocities bit for bit and the same step; with them the policy is queried at the start of the step (the
+    unpipelined kernel), although the sim carries next_action."""
+    nat, core, orc = _mods()
+    rng = np.random.default_rng(N * E)
+    table = gu.fixtures(N)
+    o, g = _pair(E, N)
+    o.s["policy"][:] = orc.POL_RVO
+    g.set_plugins(nat.POL_RVO)
+    o.reset(table[np.arange(E) % table.shape[0]])
+    for _ in range(40):
+        o.step()
+    keep = []
+    for t in range(12):
+        collab = rng.choice(np.array([0.0, -0.5, 0.5, -1.0], np.float32), (E, N))
+        noise = rng.normal(0.0, 0.5, (E, N)) * (rng.random((E, N)) < 0.5)
+        o.set_rvo_stochastic(collab, noise)
+        tc_, tn_ = torch.from_numpy(collab).to(g.device), torch.from_numpy(noise).to(g.device)
+        keep = [tc_, tn_]
+        g._cs.rvo_collab, g._cs.rvo_heading_noise = tc_.data_ptr(), tn_.data_ptr()
+        _upload(o, g)
+        o.step()
+        g.step()
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<")
+        got, want = g.orca_vel.cpu().numpy().reshape(-1, 2), o.orca_vel.reshape(-1, 2)
+        # (equal as NUMBERS: with a collaboration coefficient of exactly 0 -- the non-cooperative phase -- the products
+        # 0 * u carry u's sign, and the kernel's branch-free half-plane and the oracle's if / else form can hand an agent
+        # whose solution is the zero velocity zeros of different sign: seen for ~1 agent in 10 000, without consequence --
+        # the position advance pos + v * dt and every later use are the same)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, "step %d: %d ORCA velocities differ; first: agent %s collab %s got %s want %s flags %s" % (
+            t, bad.size, bad[:6], collab.reshape(-1)[bad[:6]], got[bad[:6]], want[bad[:6]],
+            [hex(int(f)) for f in o.s["flags"][bad[:6]]])
+        _compare(o, g, what="stochastic N=%d step %d" % (N, t))
+    # the draws matter: an agent's action with noise differs from the one without
+    assert np.abs(g.actions.cpu().numpy()[..., 1]).max() > np.pi / 6 + 0.05
+    g._cs.rvo_collab, g._cs.rvo_heading_noise = None, None
+    o.set_rvo_stochastic()
+    _upload(o, g)
+    o.step()
+    g.step()
+    _compare(o, g, what="deterministic again")
+    assert np.abs(g.actions.cpu().numpy()[..., 1]).max() <= np.pi / 6 + 1e-6
+
+
+def test_rvo_stochastic_batch_statistics():
+    """core.BatchedSim.set_rvo_stochastic: the batched device draws follow the reference's rules -- an anti-collaborative
+    agent (RVO_COLLAB_COEFF = c < 0) redraws `use_non_coop_policy` whenever its clock is within DT of a multiple of
+    RVO_ANTI_COLLAB_T (True with probability 1 - |c|, then collaboration coefficient 0, else c); heading noise is
+    N(0, 0.5) on the agents that have it and exactly 0 on the others"""
+    nat, core, orc = _mods()
+    E, N, c, T = 3000, 10, -0.7, 1.0
+    g = core.BatchedSim(core.make_params(E, N), record_actions=True)
+    g.set_plugins(nat.POL_RVO)
+    table = gu.fixtures(N)
+    g.reset(table[np.arange(E) % 500])
+    mask = np.zeros((E, N), bool)
+    mask[:, ::2] = True
+    g.set_rvo_stochastic(heading_noise=mask, collab_coeff=c, anti_collab_t=T, seed=11)
+    assert bool(g._rvo["non_coop"].all())                    # RVOPolicy.py:33: starts non-cooperative
+    prev, switched = None, {}
+    noises = []
+    for t in range(25):
+        g.step()
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<")
+        nc = g._rvo["non_coop"].cpu().numpy()
+        cf = g._rvo["collab"].cpu().numpy()
+        assert np.array_equal(cf, np.where(nc, np.float32(0.0), np.float32(c)))
+        if prev is not None:
+            switched[t] = float((nc != prev).mean())
+        prev = nc
+        noises.append(g._rvo["noise"].cpu().numpy())
+        if t in (0, 10, 20):                                  # t = 0, 1, 2 s: a redraw for everybody
+            assert abs(nc.mean() - (1 - abs(c))) < 0.02, (t, nc.mean())
+    # (step t queries at clock t * DT: everybody redraws at t = 10 and 20 -- a switch with probability 2 * 0.3 * 0.7 --; in
+    # between only an agent whose clock STOPPED on a multiple of T -- done since that step -- keeps redrawing)
+    assert all(abs(switched[t] - 0.42) < 0.03 for t in (10, 20)), switched
+    assert all(v < 0.01 for t, v in switched.items() if t not in (10, 20)), switched
+    z = np.stack(noises)
+    assert np.all(z[:, ~mask] == 0.0)
+    assert abs(z[:, mask].mean()) < 0.005 and abs(z[:, mask].std() - 0.5) < 0.005
+    # the noise reaches the actions: unclipped delta headings beyond pi / 6 appear only on the noisy agents
+    a1 = np.abs(g.actions.cpu().numpy()[..., 1])
+    assert a1[:, 1::2].max() <= np.pi / 6 + 1e-6 and a1[:, ::2].max() > np.pi / 6 + 0.1
+    assert np.isfinite(g.state["pos_x"].cpu().numpy()).all()
+    g.set_rvo_stochastic()
+    g.step()
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4")
