@@ -275,7 +275,10 @@ def respawn(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["CAGPU_BENCH_SPAWNED"] = "1"
-    sys.exit(subprocess.run(cmd, env=env).returncode)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    for line in r.stdout.decode(errors="replace").splitlines():   # stdout carries the ONE JSON line; whatever the
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")   # backends print goes to stderr
+    sys.exit(r.returncode)
 
 
 def main():
