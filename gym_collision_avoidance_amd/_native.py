@@ -35,7 +35,7 @@ class CaParams(C.Structure):
 
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
                 "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
-                "reset_count", "env_stats", "next_action", "turning_dir", "rvo_collab", "rvo_heading_noise")
+                "reset_count", "env_stats", "next_action", "turning_dir", "rvo_collab", "rvo_heading_noise", "ext_state")
 OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel")
 
 

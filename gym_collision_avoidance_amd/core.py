@@ -408,9 +408,17 @@ class BatchedSim(object):
         self.done = new(self.done); co.done = self.done.data_ptr()
         self.game_over = new(self.game_over); co.game_over = self.game_over.data_ptr()
 
-    def step(self, ext_actions=None):
+    def step(self, ext_actions=None, ext_state=None):
+        """ext_state: float64 [E, N, 5] = px, py, vx, vy, heading for agents with ExternalDynamics whose motion of THIS step
+        was integrated outside (a user Dynamics subclass on the host; NaN rows: none) -- applied by the kernel at the move
+        (CaState.ext_state); None: nobody."""
         if self._rvo is not None:
             self._rvo_draw()
+        if ext_state is not None or self._cs.ext_state:
+            self._ext_state = self._dev(ext_state, torch.float64)
+            if self._ext_state is not None:
+                assert tuple(self._ext_state.shape) == (self.E, self.N, 5), self._ext_state.shape
+            self._cs.ext_state = None if self._ext_state is None else self._ext_state.data_ptr()
         if ext_actions is None and not self._has_ga3c:
             # env.step(None) with built-in policies only (env_utils.py:50): the per-step host path is one ctypes call
             # with prebuilt arguments -- at ~20 us per launch the interpreter is otherwise on the critical path

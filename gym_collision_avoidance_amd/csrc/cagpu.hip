@@ -1124,6 +1124,12 @@ LP1_UNROLL
               r.vy = a0 * sn;
               r.heading = nh;
               if (dyn == CA_DYN_UNICYCLE) r.td = turning_dir_next(r.td, nh);
+            } else if (k.s.ext_state) {  // a host-side Dynamics subclass integrated this agent (agent.py:214-220)
+              const double* q = k.s.ext_state + 5 * i;
+              const double npx = q[0], npy = q[1], nvx = q[2], nvy = q[3], nh = q[4];
+              if (!(npx != npx || npy != npy || nvx != nvx || nvy != nvy || nh != nh)) {
+                r.px = npx; r.py = npy; r.vx = nvx; r.vy = nvy; r.heading = nh;
+              }
             }
             const double qx = r.px - r.gx, qy = r.py - r.gy;
             if (qx * qx + qy * qy <= p.near_goal_threshold * p.near_goal_threshold) r.flags |= CA_AT_GOAL;
@@ -1819,7 +1825,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
 bool pipe_eligible(const KArgs& k) {
   const int n = k.p.num_agents;
   if (!k.s.next_action || k.stage_obs) return false;
-  if (k.s.rvo_collab || k.s.rvo_heading_noise) return false;  // (per-step draws belong to the step that consumes them)
+  if (k.s.rvo_collab || k.s.rvo_heading_noise || k.s.ext_state) return false;  // (per-step inputs belong to the step that consumes them)
 #ifdef CAGPU_FAST
   if (n != 10) return false;
 #endif

@@ -36,6 +36,25 @@ _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radi
         "t", "slt", "ep_reward", "turning_dir")
 
 
+class _HostAgent(object):
+    """A mutable stand-in of an Agent for ONE call of a user Dynamics.step(action, dt): the attributes a dynamics model
+    writes (agent.py:76-96) are plain values here, everything else reads through to the bound agent."""
+
+    def __init__(self, agent):
+        object.__setattr__(self, "_agent", agent)
+        self.pos_global_frame = np.array(agent.pos_global_frame, dtype="float64")
+        self.vel_global_frame = np.array(agent.vel_global_frame, dtype="float64")
+        # (np.float64 scalars, what these attributes are in the reference once np.arctan2 / the dynamics have written them:
+        # under numpy >= 2 a float32 action plus a PYTHON float would be evaluated in float32)
+        self.heading_global_frame = np.float64(agent.heading_global_frame)
+        self.speed_global_frame = np.float64(agent.speed_global_frame)
+        self.delta_heading_global_frame = np.float64(agent.delta_heading_global_frame)
+        self.turning_dir = np.float64(agent.turning_dir)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_agent"), name)
+
+
 class CollisionAvoidanceEnv(Env):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
 
@@ -92,6 +111,7 @@ class CollisionAvoidanceEnv(Env):
         self._fixture = None
         self._all_agents = None
         self._host_policies, self._host_by_env, self._groups = [], None, []
+        self._host_dynamics, self._hostdyn_by_env, self._ext_state = [], None, None
 
     # ------------------------------------------------------------------ configuration (reference setters)
     def set_agents(self, agents):
@@ -178,7 +198,7 @@ class CollisionAvoidanceEnv(Env):
         sim.p.dt = self.dt_nominal if dt is None else float(dt)
         self.episode_step_number += 1
         ext = self._external_actions(actions)
-        sim.step(ext)
+        sim.step(ext, ext_state=self._ext_state)
         self._snap, self._obs_np, self._scan_np = None, None, None
         if Config.USE_STATIC_MAP:
             sim.laserscan()
@@ -246,19 +266,28 @@ class CollisionAvoidanceEnv(Env):
     def _plugin_ids(self, agents):
         pol, dyn, isl, stl = [], [], [], []
         self._host_policies = []   # (of the agent list this was last called for: _upload ends with env 0's)
+        self._host_dynamics = []
         for i, a in enumerate(agents):
             p = a.policy
+            custom_dyn = a.dynamics_model.kernel_id is None
             # (RVOPolicy's stochastic branches: on the host through find_next_action for a single env -- the reference's own
             # np.random calls --, in a batch as per-step device draws, core.BatchedSim.set_rvo_stochastic)
-            if type(p) in _BUILTIN_POLICIES and not (getattr(p, "needs_host", False) and self.num_envs == 1):
+            builtin = type(p) in _BUILTIN_POLICIES and not (getattr(p, "needs_host", False) and self.num_envs == 1)
+            if custom_dyn:
+                # A user-defined Dynamics subclass (the plugin API of dynamics/Dynamics.py:15-41): its step(action, dt) runs
+                # on the HOST each step with the action of that step, and the state it leaves is applied by the kernel at
+                # the move (CaState.ext_state) -- so the agent's action has to be known on the host: its policy is queried
+                # there too (every built-in policy but the GA3C-CADRL network is host-callable)
+                if isinstance(p, GA3CCADRLPolicy):
+                    raise NotImplementedError("a custom Dynamics subclass needs its agent's action on the host; "
+                                              "GA3CCADRLPolicy has no host implementation (it runs in cagpu_ga3c)")
+                self._host_dynamics.append(i)
+            if builtin and not (custom_dyn and not isinstance(p, StaticPolicy)):
                 pol.append(p.kernel_id)
             else:  # user plugin: queried on the host, handed to the kernel as a raw command
                 pol.append(nat.POL_EXTERNAL)
                 self._host_policies.append(i)
-            if a.dynamics_model.kernel_id is None:
-                raise NotImplementedError("custom Dynamics subclasses are not supported (the move happens in the "
-                                          "kernel): use Unicycle / MaxTurnRate / External")
-            dyn.append(a.dynamics_model.kernel_id)
+            dyn.append(nat.DYN_EXTERNAL if custom_dyn else a.dynamics_model.kernel_id)
             isl.append(p.str == "learning")
             stl.append(bool(p.is_still_learning))
         return pol, dyn, isl, stl
@@ -339,14 +368,15 @@ class CollisionAvoidanceEnv(Env):
                 heads = (torch.rand((E, N), generator=gen, device=sim.device, dtype=torch.float64) * 2.0 - 1.0) * np.pi
             sim.reset(f["table"][idx], headings=heads)
             groups = [agents0]
-            self._host_by_env = None
+            self._host_by_env, self._hostdyn_by_env = None, None
         else:
             sim.set_fixture_table(None)
             groups = [g if g is not None else agents0 for g in per_env]
-            ids, self._host_by_env = [], []
+            ids, self._host_by_env, self._hostdyn_by_env = [], [], []
             for g in groups:
                 ids.append(self._plugin_ids(g))
                 self._host_by_env.append(list(self._host_policies))
+                self._hostdyn_by_env.append(list(self._host_dynamics))
             self._plugin_ids(agents0)  # leaves self._host_policies describing env 0
             pad = lambda v, fill: list(v) + [fill] * (N - len(v))      # (empty slots: ids never read, rows with radius 0)
             sim.set_plugins(*[np.array([pad(x[k], 0) for x in ids]) for k in range(4)])
@@ -355,13 +385,13 @@ class CollisionAvoidanceEnv(Env):
             heads = np.array([pad([r[1] for r in g], 0.0) for g in rows], dtype=np.float64)
             sim.reset(cases, headings=heads)
         self._groups = groups
-        if E > 1 and self._fixture is not None and self._host_policies:
+        if E > 1 and self._fixture is not None and (self._host_policies or self._host_dynamics):
             # a fixture batch is built on the device from the case table: only env 0 has Agent objects to call a Python
             # policy with.  With explicit agent lists (set_agents([[...], ...]) / the default test-case function) a user
             # policy of ANY env is queried on the host each step: the slow per-agent fallback
             raise NotImplementedError("user-defined Python policies in a fixture-suite batch: hand the batch its agents "
                                       "with set_agents([agents of env 0, agents of env 1, ...]) instead")
-        if E > 1 and any(g is None for g in (per_env or [])) and self._host_policies:
+        if E > 1 and any(g is None for g in (per_env or [])) and (self._host_policies or self._host_dynamics):
             raise NotImplementedError("user-defined Python policies in a batch need one agent list per env (their policy "
                                       "objects carry per-agent state): set_agents([[...] for each env])")
         if E > 1:   # RVOPolicy.py:77-90, :118-119 for the whole batch
@@ -408,7 +438,8 @@ class CollisionAvoidanceEnv(Env):
         # batched, not zero_copy: every step writes into newly allocated output tensors, so what step() returns is the
         # caller's to keep without a copy kernel -- unless something of ours reads the observation back later (the
         # GA3C-CADRL query, a host-side policy): then the outputs are copies and ours stay private
-        host_any = bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env))
+        host_any = (bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env)) or
+                    bool(self._host_dynamics) or bool(self._hostdyn_by_env and any(self._hostdyn_by_env)))
         sim.fresh_outputs = E > 1 and not self.zero_copy and not nets and not host_any
         if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
             sm = self.static_map_filename
@@ -427,7 +458,8 @@ class CollisionAvoidanceEnv(Env):
         InternalPolicy.py:12-23, ExternalPolicy.py:14-16) are queried HERE, on the host, agent by agent and env by env,
         with the reference's arguments -- the slow fallback; built-in policies never pass through this loop."""
         E, N = self.num_envs, self._sim.N
-        host_any = bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env))
+        host_any = (bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env)) or
+                    bool(self._host_dynamics) or bool(self._hostdyn_by_env and any(self._hostdyn_by_env)))
         if actions is not None and not isinstance(actions, dict) and not host_any:
             return actions  # already [E, N, 2]
         need = [i for i, a in enumerate(self.agents) if a.policy.is_external]
@@ -454,6 +486,29 @@ class CollisionAvoidanceEnv(Env):
                     ext[e, i] = np.asarray(p.external_action_to_action(agent, raw), dtype=np.float64)
                 elif isinstance(p, InternalPolicy):
                     ext[e, i] = np.asarray(p.find_next_action(self._obs_dicts(e)[i], group, i), dtype=np.float64)   # (:319-323)
+        self._ext_state = None
+        dyn_by_env = self._hostdyn_by_env if self._hostdyn_by_env is not None else [self._host_dynamics]
+        if any(dyn_by_env):
+            # user Dynamics subclasses (Agent.take_action, agent.py:199-220): behind the done gate, step(action, dt) with
+            # the float32 action of this step on a mutable stand-in of the agent; the state it leaves travels to the
+            # kernel, which applies it at the move (CaState.ext_state)
+            dt = float(self._sim.p.dt)
+            est = np.full((E, N, 5), np.nan, dtype=np.float64)
+            for e, group in enumerate(groups):
+                for i in dyn_by_env[e] if e < len(dyn_by_env) else ():
+                    agent = group[i]
+                    if agent.is_at_goal or agent.ran_out_of_time or agent.in_collision:
+                        continue
+                    proxy = _HostAgent(agent)
+                    dm = agent.dynamics_model
+                    dm.agent = proxy
+                    try:
+                        dm.step(ext[e, i].astype(np.float32), dt)   # (`all_actions` is a float32 array, env.py:305-307)
+                    finally:
+                        dm.agent = agent
+                    est[e, i] = [proxy.pos_global_frame[0], proxy.pos_global_frame[1], proxy.vel_global_frame[0],
+                                 proxy.vel_global_frame[1], proxy.heading_global_frame]
+            self._ext_state = est
         if not batched_in:
             for i, agent in enumerate(self.agents):
                 if i in self._host_policies:
@@ -585,7 +640,8 @@ class CollisionAvoidanceEnv(Env):
         slowest workgroup of a step."""
         if self._sim is None:
             raise RuntimeError("call reset() before rollout()")
-        if any(a.policy.is_external for a in self.agents) or self._host_policies or (self._host_by_env and any(self._host_by_env)):
+        if (any(a.policy.is_external for a in self.agents) or self._host_policies or self._host_dynamics or
+                (self._host_by_env and any(self._host_by_env)) or (self._hostdyn_by_env and any(self._hostdyn_by_env))):
             raise ValueError("rollout() needs every policy to be internal (no external actions between the steps)")
         sim = self._sim
         sim.p.dt = self.dt_nominal

@@ -146,6 +146,13 @@ typedef struct CaState {
    * used: the draws belong to the step that consumes them). */
   const float *rvo_collab;
   const double *rvo_heading_noise;
+  /* Externally integrated motion, applied AT THE MOVE of this step: device float64 [E*N, 5] = px, py, vx, vy, heading, or NULL.
+   * An agent with CA_DYN_EXTERNAL whose row holds no NaN takes that state where the built-in models integrate theirs
+   * (Agent.take_action, agent.py:214-220, calls `self.dynamics_model.step(action, dt)` -- here the caller ran its own
+   * Dynamics subclass on the host with the action of this step), i.e. AFTER every policy of the step has been queried on
+   * the pre-step state, and before the at-goal test, the clocks, collisions and sensing of the same step.  Rows of NaN /
+   * agents with another dynamics id are ignored.  With it the policy is queried at the start of the step (like rvo_*). */
+  const double *ext_state;
 } CaState;
 
 /* Device pointers to what a step hands back (collision_avoidance_env.py:225-234). */

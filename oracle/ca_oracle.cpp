@@ -398,6 +398,12 @@ void step_env(const OrcParams& p, const OrcState& s, const OrcOut& o, const doub
         else td = ((td > 0.0) - (td < 0.0)) * std::max(0.0, std::fabs(td) - 0.1);
       }
     }
+    else if (s.ext_state) {  // a host-side Dynamics subclass moved this agent (agent.py:214-220: dynamics_model.step)
+      const double* q = s.ext_state + 5 * i;
+      if (!(std::isnan(q[0]) || std::isnan(q[1]) || std::isnan(q[2]) || std::isnan(q[3]) || std::isnan(q[4]))) {
+        s.pos_x[i] = q[0]; s.pos_y[i] = q[1]; s.vel_x[i] = q[2]; s.vel_y[i] = q[3]; s.heading[i] = q[4];
+      }
+    }
     const double gx = s.pos_x[i] - s.goal_x[i], gy = s.pos_y[i] - s.goal_y[i];
     if (gx * gx + gy * gy <= p.near_goal_threshold * p.near_goal_threshold) f |= ORC_AT_GOAL;  // :150-153
     else f &= ~ORC_AT_GOAL;

@@ -70,6 +70,7 @@ typedef struct {
   /* per-step inputs of RVOPolicy's stochastic branches, both nullable (RVOPolicy.py:77-90, :118-119; include/cagpu.h) */
   const float *rvo_collab;          /* [E*N] the collaboration coefficient of each agent as the ego of its query */
   const double *rvo_heading_noise;  /* [E*N] added to an RVO agent's delta heading after the pi/6 clip */
+  const double *ext_state;          /* [E*N,5] px, py, vx, vy, heading a DYN_EXTERNAL agent takes at the move (NaN row: none) */
 } OrcState;
 
 typedef struct {

@@ -46,7 +46,7 @@ class OrcState(C.Structure):
     _fields_ = [(n, _D) for n in _STATE_F64] + [("last_action", _F), ("flags", _U32), ("policy", _I32),
                                                 ("dynamics", _I32), ("step_num", _I32), ("episode_step", _I32),
                                                 ("reset_count", _I32), ("env_stats", _D), ("rvo_collab", _F),
-                                                ("rvo_heading_noise", _D)]
+                                                ("rvo_heading_noise", _D), ("ext_state", _D)]
 
 
 class OrcOut(C.Structure):
@@ -152,6 +152,14 @@ class Oracle(object):
                 self.s.pop(name, None)
             else:
                 self.s[name] = np.ascontiguousarray(np.asarray(arr, dt).reshape(-1))
+        self._bind()
+
+    def set_ext_state(self, ext_state=None):
+        """float64 [E*N, 5] = px, py, vx, vy, heading taken at the move by DYN_EXTERNAL agents (NaN rows: none), or None"""
+        if ext_state is None:
+            self.s.pop("ext_state", None)
+        else:
+            self.s["ext_state"] = np.ascontiguousarray(np.asarray(ext_state, np.float64).reshape(-1, 5))
         self._bind()
 
     def set_policies(self, policy, dynamics=None):

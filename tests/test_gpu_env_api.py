@@ -209,6 +209,66 @@ def test_batched_rvo_heading_noise_runs_on_the_device():
     assert single._host_policies == [1] and single._sim._rvo is None
 
 
+def test_custom_dynamics_subclass_runs_on_the_host_and_moves_in_the_kernel():
+    """A user Dynamics subclass (the plugin API of dynamics/Dynamics.py:15-41): its step(action, dt) is called on the host
+    with the action of the step -- behind the done gate, like Agent.take_action (agent.py:199-220) -- and the state it leaves
+    is what the kernel moves the agent to (CaState.ext_state).  A hand-written unicycle must reproduce the built-in one."""
+    Config, tc, Env = envtools.fresh("Swap4")
+    from gym_collision_avoidance_amd.envs.agent import Agent, wrap
+    from gym_collision_avoidance_amd.envs.dynamics import Dynamics, UnicycleDynamics
+    from gym_collision_avoidance_amd.envs.policies import NonCooperativePolicy, RVOPolicy
+    from gym_collision_avoidance_amd.envs.sensors import OtherAgentsStatesSensor
+
+    class MyUnicycle(Dynamics):
+        calls = 0
+
+        def step(self, action, dt):
+            MyUnicycle.calls += 1
+            a = self.agent
+            new_heading = wrap(action[1] + a.heading_global_frame)
+            velocity = action[0] * np.array([np.cos(new_heading), np.sin(new_heading)])
+            a.pos_global_frame += velocity * dt
+            a.vel_global_frame = velocity
+            a.speed_global_frame = action[0]
+            a.delta_heading_global_frame = wrap(new_heading - a.heading_global_frame)
+            a.heading_global_frame = new_heading
+
+    def scene(dyn, e=0):
+        return [Agent(-3 - 0.2 * e, 0.4, 3, -0.3, 0.3, 1.0, None, RVOPolicy, dyn, [OtherAgentsStatesSensor], 0),
+                Agent(3, 0.1 + 0.1 * e, -3, 0.6, 0.35, 0.9, None, RVOPolicy, UnicycleDynamics, [OtherAgentsStatesSensor], 1),
+                Agent(0.3, -3.0, -0.2, 3.0, 0.3, 1.1, None, NonCooperativePolicy, dyn, [OtherAgentsStatesSensor], 2)]
+
+    runs = []
+    for dyn in (MyUnicycle, UnicycleDynamics):
+        env = Env()
+        env.set_agents(scene(dyn))
+        env.reset()
+        traj = []
+        for _ in range(70):
+            env.step({})
+            traj.append([[*a.pos_global_frame, a.heading_global_frame, *a.vel_global_frame] for a in env.agents])
+        runs.append((np.array(traj), [a.is_at_goal for a in env.agents], [a.t for a in env.agents]))
+    assert MyUnicycle.calls > 60 and MyUnicycle.calls < 2 * 70          # (not called any more once its agent is at the goal)
+    # (host cos / sin against the kernel's: a last-bit difference that the ORCA encounter of agents 0 and 1 amplifies step by
+    # step, like between any two libms -- compared over the approach, before it matters; outcomes over the whole run)
+    np.testing.assert_allclose(runs[0][0][:25], runs[1][0][:25], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=0, atol=0.05)
+    assert runs[0][1] == runs[1][1] and any(runs[0][1]) and np.allclose(runs[0][2], runs[1][2])
+    # ... and in a batch with one agent list per env
+    E = 4
+    batch = Env(num_envs=E)
+    batch.set_agents([scene(MyUnicycle, e) for e in range(E)])
+    ref = Env(num_envs=E)
+    ref.set_agents([scene(UnicycleDynamics, e) for e in range(E)])
+    batch.reset()
+    ref.reset()
+    for _ in range(30):
+        batch.step(None)
+        ref.step(None)
+    for n in ("pos_x", "pos_y", "heading"):
+        np.testing.assert_allclose(batch._sim.state[n].cpu().numpy(), ref._sim.state[n].cpu().numpy(), rtol=0, atol=1e-6)
+
+
 def test_batched_fixture_suite_and_stats():
     Config, tc, Env = envtools.fresh("Bench10")
     E = 200

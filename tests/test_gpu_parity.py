@@ -1352,3 +1352,37 @@ def test_rvo_stochastic_batch_statistics():
     g.set_rvo_stochastic()
     g.step()
     assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4")
+
+
+def test_ext_state_applied_at_the_move_vs_oracle():
+    """CaState.ext_state: agents with ExternalDynamics take an externally integrated state AT THE MOVE of the step -- after
+    every policy has seen the pre-step state, before at-goal / clocks / collisions / sensing -- NaN rows and agents with
+    built-in dynamics ignore it; kernel and oracle agree (re-injected)"""
+    nat, core, orc = _mods()
+    N, E = 6, 120
+    rng = np.random.default_rng(9)
+    table = gu.fixtures(N)
+    o, g = _pair(E, N)
+    pol = np.where(rng.random((E, N)) < 0.6, orc.POL_RVO, orc.POL_NONCOOP).astype(np.int32)
+    dyn = np.where(rng.random((E, N)) < 0.4, orc.DYN_EXTERNAL, orc.DYN_UNICYCLE).astype(np.int32)
+    o.set_policies(pol, dyn)
+    g.set_plugins(pol, dyn)
+    o.reset(table[np.arange(E) % 500])
+    for _ in range(15):
+        o.step()
+    for t in range(12):
+        st = np.full((E, N, 5), np.nan)
+        move = rng.random((E, N)) < 0.7
+        cur = np.stack([o.view(n) for n in ("pos_x", "pos_y", "vel_x", "vel_y", "heading")], axis=-1)
+        st[move] = cur[move] + rng.normal(0, 0.05, (int(move.sum()), 5))
+        o.set_ext_state(st)
+        _upload(o, g)
+        o.step()
+        g.step(ext_state=st)
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_kernel<")
+        _compare(o, g, what="ext_state step %d" % t)
+    took = (dyn == orc.DYN_EXTERNAL) & move & ((o.view("flags") & (orc.AT_GOAL | orc.OUT_OF_TIME | orc.IN_COLLISION)) == 0)
+    assert took.sum() > 50
+    np.testing.assert_allclose(g.state["pos_x"].cpu().numpy()[took], st[..., 0][took], rtol=0, atol=1e-12)
+    g.step()            # without ext_state again: the pointer is cleared
+    assert g._cs.ext_state is None or not g._cs.ext_state

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_header_layout():
     from gym_collision_avoidance_amd import _native as nat
     assert ctypes.sizeof(nat.CaParams) == 8 * 4 + 17 * 8
-    assert ctypes.sizeof(nat.CaState) == 23 * 8 and nat.CaState.turning_dir.offset == 20 * 8 and nat.CaState.rvo_heading_noise.offset == 22 * 8 and ctypes.sizeof(nat.CaOut) == 6 * 8
+    assert ctypes.sizeof(nat.CaState) == 24 * 8 and nat.CaState.turning_dir.offset == 20 * 8 and nat.CaState.ext_state.offset == 23 * 8 and ctypes.sizeof(nat.CaOut) == 6 * 8
     assert nat.CaState.next_action.offset == 19 * 8 and nat.CaOut.orca_vel.offset == 5 * 8 and nat.CaParams.ragged.offset == 28
     assert ctypes.sizeof(nat.CaAutoReset) == 56 and nat.CaAutoReset.reset_obs.offset == 32
     assert nat.CaAutoReset.reset_plan.offset == 40 and nat.CaAutoReset.heading_seed.offset == 48
