@@ -85,6 +85,7 @@ class BatchedSim(object):
         self.orca_vel = z((E, N, 2), torch.float32) if record_actions else None
         self._cs = nat.CaState(**{n: self.state[n].data_ptr() for n in nat.STATE_FIELDS if n in self.state})
         self._rvo = None          # RVOPolicy's stochastic branches (set_rvo_stochastic)
+        self._variants = []       # per-agent sensor arguments beyond the primary pair (set_sensor_variants)
         if not self.pipeline:
             self._cs.next_action = None
         self._co = nat.CaOut(obs=self.obs.data_ptr(), rewards=self.rewards.data_ptr(), done=self.done.data_ptr(),
@@ -186,6 +187,33 @@ class BatchedSim(object):
             z = torch.randn((self.E, self.N), generator=r["gen"], device=self.device, dtype=torch.float64)
             r["noise"] = (z * r["std"] * r["mask"]).contiguous()
             self._cs.rvo_heading_noise = r["noise"].data_ptr()
+
+    def set_sensor_variants(self, variants=None):
+        """Agents of one batch whose OtherAgentsStatesSensor arguments differ (the reference gives every agent its own
+        sensor object: `sensor.set_args({'agent_sorting_method': ..., 'max_num_other_agents_observed': ...})`,
+        sensors/Sensor.py:19-23).  The kernels take ONE obs_clip / sort_mode per launch -- CaParams holds the primary pair --
+        so every further pair costs one cagpu_observe launch per step: `variants` = [(mask, obs_clip, sort_mode), ...] with
+        mask a bool array broadcastable to [E, N]; after every step / reset / observe the rows of the masked agents are
+        replaced by their rows under that pair.  None / []: switched off."""
+        self._variants = []
+        for mask, clip, sort in (variants or []):
+            m = torch.from_numpy(np.array(np.broadcast_to(np.asarray(mask, bool), (self.E, self.N)))).to(self.device)
+            if not (0 <= int(clip) <= self.K):
+                raise ValueError("obs_clip %d outside [0, %d]" % (clip, self.K))
+            self._variants.append((m, int(clip), int(sort), torch.empty_like(self.obs)))
+
+    def _apply_sensor_variants(self):
+        if not self._variants:
+            return
+        p, co = self.p, self._co
+        keep = (p.obs_clip, p.sort_mode, co.obs)
+        try:
+            for m, clip, sort, buf in self._variants:
+                p.obs_clip, p.sort_mode, co.obs = clip, sort, buf.data_ptr()
+                nat.check(self.lib.cagpu_observe(C.byref(p), C.byref(self._cs), C.byref(co), self._stream()))
+                self.obs[m] = buf[m]
+        finally:
+            p.obs_clip, p.sort_mode, co.obs = keep
 
     def invalidate_plan(self):
         """Forget the pipelined policy query (CaState.next_action): call after writing state tensors directly."""
@@ -357,6 +385,7 @@ class BatchedSim(object):
                                        None if h is None else h.data_ptr(), None if m is None else m.data_ptr(),
                                        self._stream()))
         self._keep = [c, h, m]  # keep alive until the stream has consumed them
+        self._apply_sensor_variants()
         return self.obs
 
     def reset_from_table(self, env_id_offset=None):
@@ -436,6 +465,8 @@ class BatchedSim(object):
             rc = fa[0](*fa[1], torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 nat.check(rc)
+            if self._variants:
+                self._apply_sensor_variants()
             return self.obs, self.rewards, self.game_over
         e = self._dev(ext_actions, torch.float64)
         if e is not None:
@@ -458,6 +489,7 @@ class BatchedSim(object):
                                           None if e is None else e.data_ptr(),
                                           None if self._ar is None else C.byref(self._ar), self._stream()))
         self._keep = [e]
+        self._apply_sensor_variants()
         return self.obs, self.rewards, self.game_over
 
     def rollout(self, n_steps, ext_actions=None):
@@ -473,6 +505,7 @@ class BatchedSim(object):
                                          None if self._ar is None else C.byref(self._ar), int(n_steps),
                                          self._stream()))
         self._keep = [e]
+        self._apply_sensor_variants()
         return self.obs, self.rewards, self.game_over
 
     def try_plan(self):
@@ -489,6 +522,7 @@ class BatchedSim(object):
         if self.fresh_outputs:   # (cagpu_observe rewrites obs only: the other outputs carry over)
             self._new_outputs(keep=True)
         nat.check(self.lib.cagpu_observe(C.byref(self.p), C.byref(self._cs), C.byref(self._co), self._stream()))
+        self._apply_sensor_variants()
         return self.obs
 
     # ---------------------------------------------------------------- statistics

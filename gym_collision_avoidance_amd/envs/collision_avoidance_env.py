@@ -292,21 +292,26 @@ class CollisionAvoidanceEnv(Env):
             stl.append(bool(p.is_still_learning))
         return pol, dyn, isl, stl
 
-    def _sensor_args(self, agents):
+    def _sensor_args(self, groups):
+        """-> (K, primary clip, primary sort id, {(clip, sort id): [(env or None, slot), ...]} of the other pairs).  Every
+        agent owns its sensor object and its arguments in the reference (sensors/Sensor.py:19-23); the pair most agents use
+        goes into CaParams, each further pair costs one cagpu_observe launch per step (core.BatchedSim.set_sensor_variants)."""
         K = Config.MAX_NUM_OTHER_AGENTS_OBSERVED
-        clip, sort = K, Config.AGENT_SORTING_METHOD
-        found = set()
-        for a in agents:
-            for s in a.sensors:
-                if getattr(s, "name", None) == "other_agents_states":
-                    found.add((min(int(s.max_num_other_agents_observed), K), s.agent_sorting_method))
-        if len(found) > 1:
-            raise NotImplementedError("per-agent sensor arguments must agree across agents: %s" % sorted(found))
-        if found:
-            clip, sort = found.pop()
-        if sort not in _SORT:
-            raise ValueError("unknown agent_sorting_method %r" % sort)
-        return K, clip, _SORT[sort]
+        per, count = {}, {}
+        for e_, g in enumerate(groups):
+            for a_, a in enumerate(g):
+                pair = (K, Config.AGENT_SORTING_METHOD)
+                for s in a.sensors:
+                    if getattr(s, "name", None) == "other_agents_states":
+                        pair = (min(int(s.max_num_other_agents_observed), K), s.agent_sorting_method)
+                if pair[1] not in _SORT:
+                    raise ValueError("unknown agent_sorting_method %r" % (pair[1],))
+                per.setdefault(pair, []).append((e_, a_))
+                count[pair] = count.get(pair, 0) + 1
+        primary = max(count, key=lambda k_: (count[k_], k_ == (K, Config.AGENT_SORTING_METHOD))) if count else \
+            (K, Config.AGENT_SORTING_METHOD)
+        others = {(c_, _SORT[s_]): v for (c_, s_), v in per.items() if (c_, s_) != primary}
+        return K, primary[0], _SORT[primary[1]], others
 
     def _upload(self, per_env):
         import torch
@@ -322,7 +327,8 @@ class CollisionAvoidanceEnv(Env):
         else:
             lens = [len(g) for g in per_env if g is not None]
             N, ragged = max(lens), len(set(lens)) > 1
-        K, clip, sort = self._sensor_args(agents0)
+        K, clip, sort, sensor_others = self._sensor_args([agents0] if (self._fixture is not None or per_env is None) else
+                                                         [g if g is not None else agents0 for g in per_env])
         over = (nat.OVER_ALL_DONE if Config.EVALUATE_MODE else
                 nat.OVER_AGENT0 if Config.TRAIN_SINGLE_AGENT else nat.OVER_LEARNING_DONE)
         key = (E, N, K, ragged)
@@ -342,6 +348,14 @@ class CollisionAvoidanceEnv(Env):
         p.reward_min, p.reward_max = self.min_possible_reward, self.max_possible_reward
         p.rvo_time_horizon, p.rvo_collab_coeff = Config.RVO_TIME_HORIZON, Config.RVO_COLLAB_COEFF
         p.max_heading_change = self.max_heading_change
+        variants = []
+        for (c_, s_), where in sensor_others.items():   # (a fixture batch / one shared agent list: a slot's pair holds for every env)
+            mask = np.zeros((E, N), dtype=bool)
+            shared = self._fixture is not None or per_env is None or any(g is None for g in per_env)
+            for e_, a_ in where:
+                mask[slice(None) if shared else e_, a_] = True
+            variants.append((mask, c_, s_))
+        sim.set_sensor_variants(variants)
         if self._fixture is not None:
             f = self._fixture
             slots = agents0 if len(agents0) == N else tc.cadrl_test_case_to_agents(

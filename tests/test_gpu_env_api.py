@@ -269,6 +269,41 @@ def test_custom_dynamics_subclass_runs_on_the_host_and_moves_in_the_kernel():
         np.testing.assert_allclose(batch._sim.state[n].cpu().numpy(), ref._sim.state[n].cpu().numpy(), rtol=0, atol=1e-6)
 
 
+def test_per_agent_sensor_arguments():
+    """every agent owns its sensor object and arguments in the reference (Sensor.set_args, sensors/Sensor.py:19-23): half of
+    the agents of a scene observe closest_first with all slots, the other half closest_last clipped to 3 -- each agent's
+    observation row must be the one a batch with ITS arguments everywhere produces (the policies here ignore the
+    observation, so the trajectories of the three runs are the same)"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    N, E = 6, 5
+    table = tc.fixture_table(N)
+    alt = {"agent_sorting_method": "closest_last", "max_num_other_agents_observed": 3}
+
+    def build(which):
+        scenes = []
+        for e in range(E):
+            agents = tc.cadrl_test_case_to_agents(table[e], policies="RVO")
+            for i, a in enumerate(agents):
+                if which == "alt" or (which == "mixed" and i % 2 == 1):
+                    a.sensors[0].set_args(alt)
+            scenes.append(agents)
+        env = Env(num_envs=E)
+        env.set_agents(scenes)
+        obs = [env.reset()[0].cpu().numpy()]
+        for _ in range(15):
+            obs.append(env.step(None)[0].cpu().numpy())
+        return np.array(obs), env
+
+    first, _ = build("first")
+    last, _ = build("alt")
+    mixed, env = build("mixed")
+    assert len(env._sim._variants) == 1
+    assert not np.allclose(first, last)
+    np.testing.assert_allclose(mixed[:, :, 0::2], first[:, :, 0::2], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(mixed[:, :, 1::2], last[:, :, 1::2], rtol=0, atol=1e-6)
+    assert np.all(mixed[:, :, 1::2, 1] <= 3) and mixed[:, :, 0::2, 1].max() == N - 1      # num_other_agents_observed
+
+
 def test_batched_fixture_suite_and_stats():
     Config, tc, Env = envtools.fresh("Bench10")
     E = 200
