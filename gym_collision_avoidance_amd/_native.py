@@ -36,7 +36,7 @@ class CaParams(C.Structure):
 STATE_FIELDS = ("pos_x", "pos_y", "vel_x", "vel_y", "heading", "goal_x", "goal_y", "radius", "pref_speed",
                 "time_remaining", "t", "slt", "ep_reward", "last_action", "flags", "step_num", "episode_step",
                 "reset_count", "env_stats", "next_action", "turning_dir", "rvo_collab", "rvo_heading_noise", "ext_state")
-OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel")
+OUT_FIELDS = ("obs", "rewards", "done", "game_over", "actions", "orca_vel", "workspace")
 
 
 class CaState(C.Structure):
@@ -44,7 +44,7 @@ class CaState(C.Structure):
 
 
 class CaOut(C.Structure):
-    _fields_ = [(n, _P) for n in OUT_FIELDS]
+    _fields_ = [(n, _P) for n in OUT_FIELDS] + [("workspace_bytes", C.c_uint64)]
 
 
 class CaAutoReset(C.Structure):
@@ -73,7 +73,7 @@ class CaNet(C.Structure):
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes")
 
 _lib = None
 
@@ -112,10 +112,12 @@ def lib():
     L.cagpu_generate_cases_ragged.argtypes = ([C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32] + [C.c_double] * 4 +
                                               [C.c_uint64, _P, _P, _P, _P])
     L.cagpu_device_faults.argtypes = [_P, C.c_int32]
+    L.cagpu_workspace_bytes.argtypes = [PP]
+    L.cagpu_workspace_bytes.restype = C.c_uint64
     L.cagpu_debug_libm.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
-        if n not in ("cagpu_last_error", "cagpu_last_kernel"):
+        if n not in ("cagpu_last_error", "cagpu_last_kernel", "cagpu_workspace_bytes"):
             getattr(L, n).restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
     L.cagpu_last_kernel.restype = C.c_char_p

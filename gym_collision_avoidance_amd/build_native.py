@@ -19,7 +19,7 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     deps = [SRC, os.path.join(HERE, "csrc", "cagpu_grouplp.inc"), os.path.join(HERE, "csrc", "cagpu_scan.inc"),
-            os.path.join(HERE, "csrc", "cagpu_ga3c.inc"), os.path.join(HERE, "csrc", "cagpu_gen.inc"), os.path.join(HERE, "csrc", "cagpu_pipe.inc"),
+            os.path.join(HERE, "csrc", "cagpu_ga3c.inc"), os.path.join(HERE, "csrc", "cagpu_gen.inc"), os.path.join(HERE, "csrc", "cagpu_pipe.inc"), os.path.join(HERE, "csrc", "cagpu_big.inc"),
             os.path.join(REPO, "include", "cagpu.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

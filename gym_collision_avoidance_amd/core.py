@@ -92,6 +92,12 @@ class BatchedSim(object):
                              game_over=self.game_over.data_ptr(),
                              actions=self.actions.data_ptr() if record_actions else None,
                              orca_vel=self.orca_vel.data_ptr() if record_actions else None)
+        # more than 64 agents per env: the large-env kernel's per-pair columns live in a workspace (include/cagpu.h)
+        self._workspace = None
+        wsb = int(self.lib.cagpu_workspace_bytes(C.byref(self.p)))
+        if wsb:
+            self._workspace = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            self._co.workspace, self._co.workspace_bytes = self._workspace.data_ptr(), wsb
         # fresh_outputs: every step / rollout writes obs, rewards, done and game_over into NEWLY allocated tensors (the
         # previous ones stay valid and belong to whoever holds them: the env API's "fresh arrays every step" without a
         # copy kernel).  Every element of the four outputs is rewritten by every step launch

@@ -1596,6 +1596,7 @@ LP1_UNROLL
 }
 
 #include "cagpu_pipe.inc"
+#include "cagpu_big.inc"
 
 // ---------------------------------------------------------------- stand-alone ORCA (rvo2 doStep replacement)
 struct OrcaArgs {
@@ -1653,7 +1654,9 @@ int fail(int code, const char* fmt, const char* detail = "") {
 int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   if (!p || !s || !o) return fail(CA_EINVAL, "cagpu: NULL params/state/out%s");
   if (p->num_envs < 1 || p->num_agents < 1) return fail(CA_EINVAL, "cagpu: num_envs and num_agents must be >= 1%s");
-  if (p->num_agents > 64) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 64 not supported yet (ORCA line tile must fit the 160 KiB LDS)%s");
+  if (p->num_agents > big::NT) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 256 is not supported (one thread per agent in the large-env kernel)%s");
+  if (p->num_agents > 64 && !o->workspace)
+    return fail(CA_EINVAL, "cagpu: num_agents > 64 runs the large-env kernel, which needs CaOut.workspace (cagpu_workspace_bytes(p) bytes)%s");
   if (p->max_obs < 0) return fail(CA_EINVAL, "cagpu: max_obs < 0%s");
   if (p->obs_clip < 0 || p->obs_clip > p->max_obs) return fail(CA_EINVAL, "cagpu: obs_clip must be in [0, max_obs]%s");
   if (p->sort_mode < CA_SORT_CLOSEST_FIRST || p->sort_mode > CA_SORT_TIME_TO_IMPACT)
@@ -1882,6 +1885,28 @@ int launch_pipe(const KArgs& k, hipStream_t st) {
   }
 }
 
+// Envs with more than 64 agents: the one-thread-per-agent kernel of cagpu_big.inc over the caller's workspace; as many
+// workgroups as the workspace holds, each walking envs e = blockIdx, blockIdx + grid, ...; a rollout is n launches.
+int launch_big(const KArgs& k0, hipStream_t st) {
+  KArgs k = k0;
+  const int N = k.p.num_agents;
+  const size_t per = big::ws_bytes_per_wg(N);
+  long wgs = static_cast<long>(k.o.workspace_bytes / per);
+  if (wgs < 1) return fail(CA_EINVAL, "cagpu: CaOut.workspace is smaller than one workgroup's share (cagpu_workspace_bytes)%s");
+  if (wgs > k.p.num_envs) wgs = k.p.num_envs;
+  const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
+  k.n_steps = 1;
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_big_kernel grid=%ld threads=%d ws_per_wg=%zu mode=%d", wgs, big::NT, per,
+                k.mode);
+  for (int s = 0; s < n_steps; ++s) {
+    hipLaunchKernelGGL(big::ca_big_kernel, dim3(static_cast<unsigned>(wgs)), dim3(big::NT), 0, st, k,
+                       static_cast<unsigned char*>(k.o.workspace), per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+  }
+  return CA_OK;
+}
+
 // Workgroup size (measured on MI355X at 4096 envs x 10 agents, profiles/r01_kernel_geometry.md): 256 threads for both the
 // single-step kernel (30.7 us; 128 -> 39, 384 / 512 -> 40) and the n-step rollout kernel (22.2 us / step; 128 -> 28.8).
 // The rollout kernel only reaches that since the build disables machine LICM (build_native.py): hoisted loop invariants
@@ -1893,6 +1918,7 @@ int launch_any(const KArgs& k0, void* stream) {
 #ifndef CAGPU_NOPIPE
   if (pipe_eligible(k)) return launch_pipe(k, st);
 #endif
+  if (k.mode != pipe::MODE_PLAN && N > 64) return launch_big(k, st);
   if (k.mode == pipe::MODE_PLAN) return fail(CA_EUNSUPPORTED, "cagpu_plan: needs CaState.next_action, num_agents in {2, 3, 4, 5, 6, 8, 10}, closest_first sorting and a grid of at most 4 x CUs or at least 8 x CUs tiles%s");
   k.tile_envs = ROW / N;
   k.col_stride = (N > 32) ? (CAGPU_CSPAD ? (N | 1) : N) : CS_ROW;  // single-env tiles: only the N columns in use (see ca_kernel)
@@ -2166,6 +2192,7 @@ int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const dou
 
 int cagpu_plan(const CaParams* p, const CaState* s, void* stream) {
   if (!p || !s) return fail(CA_EINVAL, "cagpu_plan: NULL params/state%s");
+  if (p->num_agents > 10) return fail(CA_EUNSUPPORTED, "cagpu_plan: no pipelined step kernel for more than 10 agents per env%s");
   CaOut o;
   std::memset(&o, 0, sizeof(o));
   o.obs = reinterpret_cast<float*>(1); o.rewards = o.obs; o.done = reinterpret_cast<uint8_t*>(1); o.game_over = o.done;  // (not touched in this mode)
@@ -2222,6 +2249,14 @@ int cagpu_debug_prof(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+
+uint64_t cagpu_workspace_bytes(const CaParams* p) {
+  if (!p || p->num_agents <= 64 || p->num_agents > big::NT || p->num_envs < 1) return 0;
+  long wgs = 2L * device_cus();   // two resident workgroups per CU keep the device busy; more only cost memory
+  if (wgs < 1) wgs = 512;
+  if (wgs > p->num_envs) wgs = p->num_envs;
+  return static_cast<uint64_t>(wgs) * big::ws_bytes_per_wg(p->num_agents);
+}
 
 int cagpu_device_faults(uint32_t* faults, int32_t clear) {
   if (!faults) return fail(CA_EINVAL, "cagpu_device_faults: NULL pointer%s");

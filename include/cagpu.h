@@ -168,6 +168,11 @@ typedef struct CaOut {
                         (PyRVOSimulator.doStep + getAgentVelocity, RVOPolicy.py:93) -- what cagpu_orca returns for the same
                         float inputs, bit for bit; 0 for the agents that were not queried.  Parity hook for the ORCA phases of
                         the step kernel itself. */
+  void *workspace;   /* device scratch for envs with MORE THAN 64 AGENTS, or NULL.  Up to 64 agents an env is one workgroup tile
+                        and every per-(agent, other) quantity lives in LDS; beyond that (the reference's make_testcase_huge /
+                        get_testcase_huge, test_cases.py:914-1018: 100 agents) the step runs a one-thread-per-agent kernel
+                        (num_agents <= 256) whose per-pair columns live here.  cagpu_workspace_bytes(p) says how much. */
+  uint64_t workspace_bytes;
 } CaOut;
 
 /* Fixture-table auto-reset (the batched form of vec_env.py:120-128 + test_cases.py:593-624):
@@ -335,6 +340,11 @@ int cagpu_orca(int32_t num_envs, int32_t num_agents, const float *pos, const flo
 /* Replaces: OtherAgentsStatesSensor.sense + the observation assembly (OtherAgentsStatesSensor.py:58-144,
  * agent.py:323-327) for the CURRENT state, without stepping: rewrites o->obs only. */
 int cagpu_observe(const CaParams *p, const CaState *s, const CaOut *o, void *stream);
+
+/* Bytes of CaOut.workspace the step / reset / observe / rollout calls want for these parameters: 0 up to 64 agents per env,
+ * otherwise one share (15 360 B x num_agents) per workgroup of the large-env kernel, for min(num_envs, 2 x CUs) workgroups
+ * (a smaller workspace works too: fewer workgroups walk the envs).  Host-only call. */
+uint64_t cagpu_workspace_bytes(const CaParams *p);
 
 /* Device-side fault word of the CURRENT device (synchronises it): bit 0 = a bounded hand-over poll inside the pipelined
  * step kernel ran out (csrc/cagpu_pipe.inc wait_for), i.e. some launch since the last clear may have produced wrong state.

@@ -29,6 +29,10 @@ class Bench10(_Eval):
     N_MAX = 10
 
 
+class Huge100(_Eval):     # the reference's get_testcase_huge shape: 100 agents in one env, 19 observed (the GA3C-CADRL width)
+    N_MAX, K = 100, 19
+
+
 class Swap4(_Eval):
     N_MAX = 4
 

@@ -1386,3 +1386,80 @@ def test_ext_state_applied_at_the_move_vs_oracle():
     np.testing.assert_allclose(g.state["pos_x"].cpu().numpy()[took], st[..., 0][took], rtol=0, atol=1e-12)
     g.step()            # without ext_state again: the pointer is cleared
     assert g._cs.ext_state is None or not g._cs.ext_state
+
+
+# ---------------------------------------------------------------- more than 64 agents per env (csrc/cagpu_big.inc)
+@pytest.mark.parametrize("N,E,K,sort,ragged", [(100, 5, 99, 0, 0), (70, 9, 19, 1, 1), (65, 4, 10, 2, 0), (128, 3, 30, 0, 0)])
+def test_big_envs_vs_oracle(N, E, K, sort, ragged):
+    """Envs beyond one workgroup tile -- the reference's make_testcase_huge / get_testcase_huge scenes (test_cases.py:914-1018;
+    100 agents in its shipped case) -- run the one-thread-per-agent kernel over CaOut.workspace: reset, re-injected steps with
+    every built-in policy / dynamics, all three sort modes, ragged slots, auto-reset from a table, against the oracle; the
+    ORCA velocities bit for bit (the serial programme of cagpu_orca)."""
+    nat, core, orc = _mods()
+    from gym_collision_avoidance_amd.envs import test_cases as tc
+    rng = np.random.default_rng(N + E)
+    np.random.seed(N)
+    # (a quarter of the square covered by the 2 m clearance discs: the rejection sampler of make_testcase_huge stays quick)
+    table = tc.make_testcase_huge(E + 3, N, side_length=2.0 * np.sqrt(N) + 3.0, speed_bnds=[0.5, 1.5], radius_bnds=[0.2, 0.5])
+    if ragged:
+        for c in range(table.shape[0]):
+            table[c, N - int(rng.integers(0, N // 3)):] = 0.0       # (padding rows: radius 0 = empty slots)
+    # (game over when agent 0 is done and short clocks: time-outs, goals and auto-resets all fall into the compared window)
+    o, g = _pair(E, N, K, sort_mode=sort, ragged=ragged, max_time_ratio=0.25, game_over_mode=1)
+    assert g._workspace is not None and g._workspace.numel() == int(nat.lib().cagpu_workspace_bytes(g.p))
+    pol = rng.choice([orc.POL_RVO, orc.POL_RVO, orc.POL_RVO, orc.POL_NONCOOP, orc.POL_STATIC, orc.POL_EXTERNAL,
+                      orc.POL_LEARNING], (E, N)).astype(np.int32)
+    dyn = rng.choice([orc.DYN_UNICYCLE, orc.DYN_UNICYCLE, orc.DYN_MAX_TURN_RATE], (E, N)).astype(np.int32)
+    o.set_policies(pol, dyn)
+    g.set_plugins(pol, dyn)
+    g.set_fixture_table(table)
+    o.reset(table[:E])
+    g.reset(table[:E])
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_big_kernel")
+    _compare_reset(o, g)
+    ended = 0
+    for t in range(45):
+        ext = rng.uniform(0.0, 1.0, (E, N, 2))
+        _upload(o, g)
+        o.rollout_ex(table, 1, ext_actions=ext)
+        g.step(ext)
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_big_kernel")
+        live = (o.s["policy"] == orc.POL_RVO)
+        got, want = g.orca_vel.cpu().numpy().reshape(-1, 2), o.orca_vel.reshape(-1, 2)
+        assert np.array_equal(got, want), "step %d: %d ORCA velocities differ" % (t, (got != want).any(1).sum())
+        _compare(o, g, what="N=%d step %d" % (N, t))
+        ended += int(o.game_over.sum())
+    assert ended > 0 and live.any()
+    # observe() and a fused rollout (n launches of the same kernel) on the same path
+    before = g.obs.clone()
+    g.obs.zero_()
+    assert torch.equal(g.observe(), before)
+    h = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=sort, ragged=ragged, max_time_ratio=0.25, game_over_mode=1))
+    h.set_plugins(np.where(pol >= orc.POL_EXTERNAL, orc.POL_NONCOOP, pol), dyn)
+    h.set_fixture_table(table)
+    g.set_plugins(np.where(pol >= orc.POL_EXTERNAL, orc.POL_NONCOOP, pol), dyn)
+    for n in F64 + ("flags", "step_num", "episode_step", "reset_count", "last_action"):
+        h.state[n].copy_(g.state[n])
+    h.set_plugins(np.where(pol >= orc.POL_EXTERNAL, orc.POL_NONCOOP, pol), dyn)
+    g.rollout(4)
+    for _ in range(4):
+        h.step()
+    for n in ("pos_x", "pos_y", "heading", "flags"):
+        assert torch.equal(g.state[n], h.state[n]), n
+
+
+def test_big_envs_through_the_env_api():
+    """the reference's get_testcase_huge shape through the gym-level API: 100 RVO agents in one env"""
+    from tests import envtools
+    Config, tc, Env = envtools.fresh("Huge100")
+    np.random.seed(5)
+    case = tc.make_testcase_huge(1, 100, side_length=25)[0]      # (the reference's own default side length)
+    env = Env()
+    env.set_agents(tc.cadrl_test_case_to_agents(case, policies="RVO"))
+    obs, _ = env.reset()
+    assert obs[0]["other_agents_states"].shape == (Config.MAX_NUM_OTHER_AGENTS_OBSERVED, 7)
+    d0 = np.array([a.dist_to_goal for a in env.agents])
+    for _ in range(40):
+        obs, rew, over, _, info = env.step({})
+    d1 = np.array([a.dist_to_goal for a in env.agents])
+    assert rew.shape == (100,) and (d1 < d0 - 1.0).mean() > 0.8 and len(info["which_agents_done"]) == 100
