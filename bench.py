@@ -180,7 +180,8 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
         out["config"]["workload"] = ("configs[2]: %d envs/GPU x %d agents, GA3CCADRLPolicy (IROS18 checkpoint, LSTM-64 + "
                                      "3 x FC-256, argmax of 11 actions) + UnicycleDynamics + OtherAgentsStatesSensor K=19 "
                                      "closest_last, fixture n20 (reference generator, seed 0), auto-reset; one cagpu_ga3c "
-                                     "+ one cagpu_step launch per step" % (E, N))
+                                     "+ one cagpu_step launch per step%s" % (E, N, "; FUSED sensing: the network kernel computes its "
+                                     "observation rows from the state (obs = NULL)" if a.ga3c_fused else ""))
         out["roofline"] = {"bound": "mfma", "achieved": flops / infer_s / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                            "kernel": "ga3c::ga3c_kernel", "avg_launch_us": infer_s * 1e6,
@@ -294,6 +295,9 @@ def main():
                          "K launches captured once into a HIP graph and replayed (one launch per env.step, no per-call "
                          "submission); rollout: all K steps fused in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ga3c-fused", action="store_true",
+                    help="ga3c20: cagpu_ga3c computes the observation rows it needs from the state itself (obs = NULL: sensing + "
+                         "inference fused in one kernel) instead of reading the rows the step kernel stored")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="A/B: without CaState.next_action, i.e. the unpipelined step kernel (policy query at the start of the step)")
     ap.add_argument("--min-warm-seconds", type=float, default=0.3,
@@ -343,6 +347,7 @@ def main():
 
     E = a.envs
     sim, table, N, K = build_workload(a.workload, E, dev, rank, world, pipeline=not a.no_pipeline, agents=a.agents)
+    sim.ga3c_fused = bool(a.ga3c_fused)
     off, stride = shard_env_ids(rank, world, E)
 
     graph = {}

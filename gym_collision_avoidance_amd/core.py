@@ -110,6 +110,7 @@ class BatchedSim(object):
         self._map = None
         self._scan = None
         self.scan = None
+        self.ga3c_fused = False   # cagpu_ga3c with obs = NULL: sensing fused into the network kernel (see ga3c())
         self._net = None          # GA3C-CADRL weights (load_ga3c); _nets: {checkpoint index: (CaNet, tensors)}
         self._net_tensors = None
         self._nets = {}
@@ -289,9 +290,13 @@ class BatchedSim(object):
             raise nat.CagpuError("GA3C-CADRL checkpoint index %s assigned but not loaded" % sorted(missing))
         self._agent_net = torch.from_numpy(a).to(self.device)
 
-    def ga3c(self, ext=None):
+    def ga3c(self, ext=None, fused=None):
         """Query the network for every live GA3C-CADRL agent on the CURRENT observation; the action indices land in
-        `ext[..., 0]` (a float64 [E,N,2] tensor, allocated here if not given), which step() then consumes."""
+        `ext[..., 0]` (a float64 [E,N,2] tensor, allocated here if not given), which step() then consumes.
+        fused (default: self.ga3c_fused): the kernel computes the ego-centric observation of the agents it evaluates from
+        the state arrays itself (cagpu_ga3c with obs = NULL: "obs + network inference fused in-kernel") instead of reading
+        the rows the last step stored -- same bits; needs num_agents <= 32, no time_to_impact sorting and no per-agent
+        sensor variants."""
         if self._net is None:
             raise nat.CagpuError("GA3C-CADRL agents present but no network loaded: call load_ga3c() "
                                  "(policy.initialize_network() in the env API)")
@@ -300,14 +305,18 @@ class BatchedSim(object):
                 self._ga3c_ext = torch.zeros((self.E, self.N, 2), dtype=torch.float64, device=self.device)
             ext = self._ga3c_ext
         lg = None if self.ga3c_logits is None else self.ga3c_logits.data_ptr()
+        fused = self.ga3c_fused if fused is None else fused
+        if fused and (self.N > 32 or self.p.sort_mode == nat.SORT_TIME_TO_IMPACT or self._variants):
+            fused = False
+        obs_ptr = None if fused else self.obs.data_ptr()
         if self._agent_net is None:      # one checkpoint (index 0) for every GA3C-CADRL agent
-            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(self._net),
+            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), obs_ptr, C.byref(self._net),
                                           ext.data_ptr(), lg, self._stream()))
             return ext
         for idx in sorted(self._nets):   # one launch per checkpoint, each over its own agents (CaNet.agent_net / net_index)
             net = self._nets[idx][0]
             net.agent_net, net.net_index = self._agent_net.data_ptr(), idx
-            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), self.obs.data_ptr(), C.byref(net),
+            nat.check(self.lib.cagpu_ga3c(C.byref(self.p), C.byref(self._cs), obs_ptr, C.byref(net),
                                           ext.data_ptr(), lg, self._stream()))
             net.agent_net = None
         return ext

@@ -2076,7 +2076,15 @@ int cagpu_laserscan(const CaParams* p, const CaState* s, const CaMap* map, const
 
 int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNet* net, double* ext_actions, float* logits,
                void* stream) {
-  if (!p || !s || !obs || !net || !ext_actions) return fail(CA_EINVAL, "cagpu_ga3c: NULL argument%s");
+  if (!p || !s || !net || !ext_actions) return fail(CA_EINVAL, "cagpu_ga3c: NULL argument%s");
+  if (!obs) {  // fused sensing: the kernel computes the observation rows it needs from the state
+    if (p->num_agents > 32 || p->sort_mode == CA_SORT_TIME_TO_IMPACT)
+      return fail(CA_EUNSUPPORTED, "cagpu_ga3c: fused sensing (obs == NULL) needs num_agents <= 32 and closest_first / closest_last sorting%s");
+    if (p->obs_clip < 0 || p->obs_clip > p->max_obs) return fail(CA_EINVAL, "cagpu_ga3c: obs_clip must be in [0, max_obs]%s");
+    const void* q[] = {s->pos_x, s->pos_y, s->vel_x, s->vel_y, s->heading, s->goal_x, s->goal_y, s->radius, s->pref_speed};
+    for (const void* x : q)
+      if (!x) return fail(CA_EINVAL, "cagpu_ga3c: fused sensing needs the state arrays%s");
+  }
   if (p->num_envs < 1 || p->num_agents < 1 || p->max_obs < 0) return fail(CA_EINVAL, "cagpu_ga3c: bad sizes%s");
   if (!s->flags) return fail(CA_EINVAL, "cagpu_ga3c: NULL state pointer%s");
   const void* w[] = {net->lstm_kernel, net->lstm_bias, net->layer1_kernel, net->layer1_bias, net->layer2_kernel,
@@ -2087,6 +2095,10 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   ga3c::Args k;
   std::memset(&k, 0, sizeof(k));
   k.obs = obs; k.flags = s->flags;
+  k.pos_x = s->pos_x; k.pos_y = s->pos_y; k.vel_x = s->vel_x; k.vel_y = s->vel_y; k.heading = s->heading;
+  k.goal_x = s->goal_x; k.goal_y = s->goal_y; k.radius = s->radius; k.pref_speed = s->pref_speed;
+  k.N = p->num_agents; k.K = p->max_obs; k.obs_clip = p->obs_clip; k.sort_mode = p->sort_mode; k.ragged = p->ragged;
+  k.sensing_horizon = p->sensing_horizon;
   k.B = static_cast<long>(p->num_envs) * p->num_agents;
   k.W = 6 + 7 * p->max_obs;
   k.net = *net; k.ext = ext_actions; k.logits = logits;

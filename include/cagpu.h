@@ -282,7 +282,10 @@ int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const
  * the first num_other_agents of the 19 other-agent slots, three 256-wide ReLU layers, logits_p; the argmax (index into
  * network.Actions, network.py:7-16) goes to ext_actions[e,n,0] (and 0 to [e,n,1]), where cagpu_step turns it into
  * [pref_speed * a0, a1] exactly as for CA_POL_LEARNING_GA3C.  obs: device float [E,N,6+7*max_obs], the observation of
- * the CURRENT state (what the reference hands to the policy, collision_avoidance_env.py:319-323).  logits (nullable):
+ * the CURRENT state (what the reference hands to the policy, collision_avoidance_env.py:319-323) -- or NULL: FUSED SENSING,
+ * the kernel computes the ego-centric observation of every agent it evaluates from the state arrays itself
+ * (OtherAgentsStatesSensor.sense + the observation assembly, with p->obs_clip / sort_mode / sensing_horizon), bit-identical to
+ * the stored row; needs num_agents <= 32 and closest_first / closest_last sorting.  logits (nullable):
  * device float [E,N,11], written for the same agents.  fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 like the
  * TF graph. */
 int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNet *net, double *ext_actions,
