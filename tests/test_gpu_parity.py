@@ -424,8 +424,10 @@ def test_too_many_agents_is_a_loud_error():
     nat, core, orc = _mods()
     with pytest.raises(nat.CagpuError):
         core.orca(*(torch.zeros(s, device="cuda") for s in ((2, 70, 2), (2, 70, 2), (2, 70, 2), (2, 70), (2, 70))))
+    core.BatchedSim(core.make_params(2, 65)).observe()       # (65 .. 256 agents: the large-env kernel, csrc/cagpu_big.inc)
+    assert nat.lib().cagpu_last_kernel().decode().startswith("ca_big_kernel")
     with pytest.raises(nat.CagpuError):
-        core.BatchedSim(core.make_params(2, 65)).observe()
+        core.BatchedSim(core.make_params(2, 257)).observe()  # one thread per agent ends at 256
 
 
 # ---------------------------------------------------------------- static map + LaserScanSensor (config 5 row)
