@@ -374,3 +374,51 @@ def test_scenario_builders_match_the_reference():
     assert len(a) == 1 and a[0].radius == 0.5 and a[0].pref_speed == 1.0
     with pytest.raises(ValueError):
         tc.preset_testCases(7)
+
+
+def test_plugin_descriptors_of_user_classes_and_sensor_argument_groups():
+    """host logic of the round-4 plugin surface, without a device: a user Dynamics subclass becomes an ExternalDynamics slot
+    whose agent is also queried on the host; per-agent sensor arguments are grouped into the pair most agents use (CaParams)
+    and the further pairs (one cagpu_observe launch each); the mutable agent stand-in a user Dynamics.step writes to keeps
+    float64 arithmetic under numpy >= 2"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    from gym_collision_avoidance_amd import _native as nat
+    from gym_collision_avoidance_amd.envs import collision_avoidance_env as cae
+    from gym_collision_avoidance_amd.envs.agent import Agent
+    from gym_collision_avoidance_amd.envs.dynamics import Dynamics, UnicycleDynamics
+    from gym_collision_avoidance_amd.envs.policies import InternalPolicy, NonCooperativePolicy, RVOPolicy, StaticPolicy
+    from gym_collision_avoidance_amd.envs.sensors import OtherAgentsStatesSensor
+
+    class MyDyn(Dynamics):
+        def step(self, action, dt):
+            self.agent.heading_global_frame = action[1] + self.agent.heading_global_frame
+
+    class MyPol(InternalPolicy):
+        def find_next_action(self, obs, agents, i):
+            return np.zeros(2)
+
+    mk = lambda i, pol, dyn: Agent(float(i), 0.0, 5.0, float(i), 0.3, 1.0, None, pol, dyn, [OtherAgentsStatesSensor], i)
+    agents = [mk(0, RVOPolicy, UnicycleDynamics), mk(1, RVOPolicy, MyDyn), mk(2, MyPol, UnicycleDynamics),
+              mk(3, StaticPolicy, MyDyn), mk(4, NonCooperativePolicy, UnicycleDynamics)]
+    env = Env()
+    pol, dyn, isl, stl = env._plugin_ids(agents)
+    assert pol == [nat.POL_RVO, nat.POL_EXTERNAL, nat.POL_EXTERNAL, nat.POL_STATIC, nat.POL_NONCOOP]
+    assert dyn == [nat.DYN_UNICYCLE, nat.DYN_EXTERNAL, nat.DYN_UNICYCLE, nat.DYN_EXTERNAL, nat.DYN_UNICYCLE]
+    assert env._host_policies == [1, 2] and env._host_dynamics == [1, 3]
+    # sensor arguments: three agents on the default pair, two on (3, closest_last)
+    for a in agents[3:]:
+        a.sensors[0].set_args({"agent_sorting_method": "closest_last", "max_num_other_agents_observed": 3})
+    K, clip, sort, others = env._sensor_args([agents])
+    assert (K, clip, sort) == (Config.MAX_NUM_OTHER_AGENTS_OBSERVED, Config.MAX_NUM_OTHER_AGENTS_OBSERVED, nat.SORT_CLOSEST_FIRST)
+    assert others == {(3, nat.SORT_CLOSEST_LAST): [(0, 3), (0, 4)]}
+    agents[0].sensors[0].set_args({"agent_sorting_method": "by_colour"})
+    with pytest.raises(ValueError):
+        env._sensor_args([agents])
+    # the stand-in: plain mutable attributes, np.float64 scalars, everything else read through
+    proxy = cae._HostAgent(agents[1])
+    MyDyn(proxy).step(np.array([1.0, 0.1], dtype=np.float32), 0.1)
+    assert isinstance(proxy.heading_global_frame, np.float64)
+    assert abs(float(proxy.heading_global_frame) - (float(np.float32(0.1)) + agents[1].heading_global_frame)) < 1e-15
+    proxy.pos_global_frame += 1.0
+    assert np.allclose(agents[1].pos_global_frame, [1.0, 0.0]) and np.allclose(proxy.pos_global_frame, [2.0, 1.0])
+    assert proxy.pref_speed == agents[1].pref_speed and proxy.id == 1
