@@ -657,6 +657,48 @@ def test_ga3c_logits_and_actions_vs_numpy_network(E, N, K):
     assert np.array_equal(g.ga3c_logits.cpu().numpy(), got) and np.array_equal(ext2.cpu().numpy(), ex)
 
 
+@pytest.mark.parametrize("live_rows", [16000, 20000, 24500, 27000, 30000, 32768, 33000, 50000, 81920])
+def test_ga3c_balanced_tile_heights_cover_every_row(live_rows):
+    """ga3c_kernel spreads the live rows' 16-row blocks evenly over the tiles of its rounds (64 / 48 / 32-row tiles in one
+    launch, csrc/cagpu_ga3c.inc tile_of): at row counts on every branch of that plan -- uniform 32-row tiles, lo = 2 / 3
+    with and without a remainder, exactly one full round, two and three rounds -- every live row is evaluated, no other row
+    is touched, the logits are those of the numpy network and bit for bit those of the unpacked launch (another plan)"""
+    nat, core, orc = _mods()
+    from oracle.ga3c_ref import GA3CNet
+    E, N, K = 4096, 20, 19
+    rng = np.random.default_rng(live_rows)
+    g = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=1))
+    g.set_plugins(nat.POL_GA3C_CADRL)
+    live = np.zeros(E * N, bool)
+    live[rng.permutation(E * N)[:live_rows]] = True
+    live = live.reshape(E, N)
+    g.state["flags"] |= torch.from_numpy(np.where(live, 0, nat.DONE).astype(np.int32)).to(g.device)
+    obs = _ga3c_obs(rng, E, N, K)
+    g.obs.copy_(torch.from_numpy(obs))
+    g.load_ga3c(keep_logits=True)
+    g.ga3c_logits.fill_(-777.0)
+    ext = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
+    g.ga3c(ext)
+    torch.cuda.synchronize()
+    assert g.ga3c_rows() == live_rows
+    got = g.ga3c_logits.cpu().numpy()
+    ex = ext.cpu().numpy()
+    assert np.all(got[~live] == -777.0) and np.all(ex[~live] == -7.0)
+    assert np.all(got[live] != -777.0) and np.all(ex[live][:, 1] == 0.0)
+    assert np.array_equal(ex[live][:, 0], np.argmax(got[live], axis=1))
+    pick = np.flatnonzero(live.reshape(-1))
+    pick = pick[rng.permutation(pick.size)[:1500]]
+    net = GA3CNet()
+    want = net.logits(net.policy_vector(obs.reshape(E * N, -1)[pick]))
+    np.testing.assert_allclose(got.reshape(E * N, 11)[pick], want, rtol=1e-4, atol=2e-4)
+    g._net.rows_scratch = None
+    g.ga3c_logits.fill_(-777.0)
+    ext2 = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
+    g.ga3c(ext2)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.ga3c_logits.cpu().numpy(), got) and np.array_equal(ext2.cpu().numpy(), ex)
+
+
 def test_ga3c_needs_loaded_network():
     nat, core, orc = _mods()
     g = core.BatchedSim(core.make_params(2, 3, max_obs=19))
