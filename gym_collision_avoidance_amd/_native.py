@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 8   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 9   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -69,11 +69,12 @@ NET_FIELDS = ("lstm_kernel", "lstm_bias", "layer1_kernel", "layer1_bias", "layer
 
 class CaNet(C.Structure):
     _fields_ = [(n, _P) for n in NET_FIELDS] + [("rows_scratch", _P), ("agent_net", _P), ("net_index", C.c_int32),
-                                                ("reserved0", C.c_int32)]
+                                                ("reserved0", C.c_int32), ("packed", _P)]
 
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
-           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes")
+           "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes",
+           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack")
 
 _lib = None
 
@@ -114,10 +115,13 @@ def lib():
     L.cagpu_device_faults.argtypes = [_P, C.c_int32]
     L.cagpu_workspace_bytes.argtypes = [PP]
     L.cagpu_workspace_bytes.restype = C.c_uint64
+    L.cagpu_ga3c_packed_bytes.argtypes = []
+    L.cagpu_ga3c_packed_bytes.restype = C.c_uint64
+    L.cagpu_ga3c_pack.argtypes = [C.POINTER(CaNet), _P, C.c_uint64, _P]
     L.cagpu_debug_libm.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, _P]
     for n in EXPORTS:
         getattr(L, n)  # AttributeError if a declared symbol is missing
-        if n not in ("cagpu_last_error", "cagpu_last_kernel", "cagpu_workspace_bytes"):
+        if n not in ("cagpu_last_error", "cagpu_last_kernel", "cagpu_workspace_bytes", "cagpu_ga3c_packed_bytes"):
             getattr(L, n).restype = C.c_int
     L.cagpu_last_error.restype = C.c_char_p
     L.cagpu_last_kernel.restype = C.c_char_p

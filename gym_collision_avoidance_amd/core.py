@@ -270,7 +270,10 @@ class BatchedSim(object):
             ts[f] = torch.from_numpy(a).to(self.device)
         # scratch of cagpu_ga3c: the packed list of the agents that need an action this step (+ their count)
         ts["rows_scratch"] = torch.zeros((self.E * self.N + 3,), dtype=torch.int32, device=self.device)
-        net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch",)})
+        # the four big matrices as bf16 planes in matrix-core fragment order: split once per checkpoint on the device
+        ts["packed"] = torch.empty((int(self.lib.cagpu_ga3c_packed_bytes()),), dtype=torch.uint8, device=self.device)
+        net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch", "packed")})
+        nat.check(self.lib.cagpu_ga3c_pack(C.byref(net), ts["packed"].data_ptr(), ts["packed"].numel(), self._stream()))
         self._nets[int(index)] = (net, ts)
         if int(index) == 0 or self._net is None:
             self._net_tensors, self._net = ts, net

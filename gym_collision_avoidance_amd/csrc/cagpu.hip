@@ -2092,6 +2092,8 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
                      net->input_mean, net->input_std};
   for (const void* q : w)
     if (!q || (reinterpret_cast<uintptr_t>(q) & 15)) return fail(CA_EINVAL, "cagpu_ga3c: NULL or not 16-byte aligned weight pointer%s");
+  if (!net->packed || (reinterpret_cast<uintptr_t>(net->packed) & 15))
+    return fail(CA_EINVAL, "cagpu_ga3c: CaNet.packed is NULL or not 16-byte aligned (fill it once per checkpoint with cagpu_ga3c_pack)%s");
   ga3c::Args k;
   std::memset(&k, 0, sizeof(k));
   k.obs = obs; k.flags = s->flags;
@@ -2261,6 +2263,30 @@ int cagpu_debug_prof(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+
+uint64_t cagpu_ga3c_packed_bytes(void) { return static_cast<uint64_t>(ga3c::PK_TOTAL) * sizeof(ga3c::u32x4); }
+
+int cagpu_ga3c_pack(const CaNet* net, void* packed, uint64_t bytes, void* stream) {
+  if (!net || !packed) return fail(CA_EINVAL, "cagpu_ga3c_pack: NULL argument%s");
+  if (bytes < cagpu_ga3c_packed_bytes() || (reinterpret_cast<uintptr_t>(packed) & 15))
+    return fail(CA_EINVAL, "cagpu_ga3c_pack: the buffer must hold cagpu_ga3c_packed_bytes() bytes, 16-byte aligned%s");
+  if (!net->lstm_kernel || !net->layer1_kernel || !net->layer2_kernel || !net->fc1_kernel)
+    return fail(CA_EINVAL, "cagpu_ga3c_pack: NULL weight pointer%s");
+  ga3c::u32x4* out = static_cast<ga3c::u32x4*>(packed);
+  struct { const float* w; int row0, k_real, nkb, at; } jobs[4] = {
+      {net->lstm_kernel, 7, 64, 2, ga3c::PK_LSTM},     // rows 0..6 (x_t) stay float32
+      {net->layer1_kernel, 4, 64, 2, ga3c::PK_L1},     // rows 0..3 (host) stay float32
+      {net->layer2_kernel, 0, 256, 8, ga3c::PK_L2},
+      {net->fc1_kernel, 0, 256, 8, ga3c::PK_FC1}};
+  for (const auto& j : jobs) {
+    const int threads = j.nkb * 16 * 64;
+    hipLaunchKernelGGL(ga3c::pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), j.w,
+                       j.row0, j.k_real, j.nkb, out + j.at);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_ga3c_pack: kernel launch failed: %s", hipGetErrorString(e));
+  return CA_OK;
+}
 
 uint64_t cagpu_workspace_bytes(const CaParams* p) {
   if (!p || p->num_agents <= 64 || p->num_agents > big::NT || p->num_envs < 1) return 0;

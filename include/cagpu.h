@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 8
+#define CAGPU_VERSION 9
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -236,6 +236,11 @@ typedef struct CaNet {
    * distinct checkpoint (each writes its own agents' entries of ext_actions).  NULL: every live GA3C-CADRL agent. */
   const int32_t *agent_net;
   int32_t net_index, reserved0;
+  /* The four big weight matrices as bf16 planes in matrix-core fragment order: device buffer of cagpu_ga3c_packed_bytes()
+   * bytes (16-byte aligned), filled ONCE per checkpoint by cagpu_ga3c_pack() from the float32 arrays above (which cagpu_ga3c
+   * still reads for the x_t / host inputs, the biases and the logits layer).  Required: cagpu_ga3c fails with CA_EINVAL
+   * without it.  The network computes on float32 operands split EXACTLY into three bf16 planes; see cagpu_ga3c. */
+  const void *packed;
 } CaNet;
 
 int cagpu_version(void);
@@ -286,10 +291,22 @@ int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const
  * the kernel computes the ego-centric observation of every agent it evaluates from the state arrays itself
  * (OtherAgentsStatesSensor.sense + the observation assembly, with p->obs_clip / sort_mode / sensing_horizon), bit-identical to
  * the stored row; needs num_agents <= 32 and closest_first / closest_last sorting.  logits (nullable):
- * device float [E,N,11], written for the same agents.  fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 like the
- * TF graph. */
+ * device float [E,N,11], written for the same agents.  Arithmetic: float32 like the TF graph, on the BF16 matrix cores
+ * (v_mfma_f32_16x16x32_bf16, f32 accumulate): both operands of every contraction are split exactly into three bf16 planes
+ * (x = hi + mid + lo) and the six largest of the nine plane products are accumulated -- a product is off by less than
+ * 2^-21 of itself (an f32 multiply: 2^-24); the x_t / host inputs and the logits layer run on the exact f32 MFMA
+ * (v_mfma_f32_16x16x4_f32).  Logits agree with a float32 evaluation of the graph to ~1e-6 (tests: rtol 1e-4, atol 2e-4).
+ * Needs net->packed (cagpu_ga3c_pack). */
 int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNet *net, double *ext_actions,
                float *logits, void *stream);
+
+/* The size of CaNet.packed, and the one-time split of a checkpoint's weights into it: reads net->lstm_kernel,
+ * layer1_kernel, layer2_kernel, fc1_kernel (device float32, the checkpoint's [in, out] layout) and writes `bytes` =
+ * cagpu_ga3c_packed_bytes() bytes at `packed` (device, 16-byte aligned).  Replaces nothing in the reference (TF keeps its
+ * variables in one layout); it is this library's equivalent of GA3CCADRLPolicy.initialize_network's checkpoint restore
+ * (GA3CCADRLPolicy.py:23-47).  Call again after changing a weight array. */
+uint64_t cagpu_ga3c_packed_bytes(void);
+int cagpu_ga3c_pack(const CaNet *net, void *packed, uint64_t bytes, void *stream);
 
 /* Replaces: generate_rand_test_case_multi (envs/policies/CADRL/scripts/multi/gen_rand_testcases.py:111-444) behind
  * test_cases.get_testcase_random (envs/test_cases.py:212-253), for num_cases scenarios at once: 15 % two-agent swap +

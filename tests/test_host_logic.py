@@ -41,7 +41,7 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(nat.CaAutoReset) == 56 and nat.CaAutoReset.reset_obs.offset == 32
     assert nat.CaAutoReset.reset_plan.offset == 40 and nat.CaAutoReset.heading_seed.offset == 48
     assert nat.CaParams.dt.offset == 32
-    assert ctypes.sizeof(nat.CaNet) == 15 * 8 and nat.CaNet.rows_scratch.offset == 12 * 8 and nat.CaNet.net_index.offset == 14 * 8
+    assert ctypes.sizeof(nat.CaNet) == 16 * 8 and nat.CaNet.rows_scratch.offset == 12 * 8 and nat.CaNet.net_index.offset == 14 * 8 and nat.CaNet.packed.offset == 15 * 8
     assert ctypes.sizeof(nat.CaMap) == 8 + 2 * 4 + 3 * 8 and nat.CaMap.cell.offset == 16
     assert ctypes.sizeof(nat.CaScan) == 2 * 8 + 4 * 4 + 4 * 8 and nat.CaScan.min_angle.offset == 32
 
