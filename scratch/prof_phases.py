@@ -24,7 +24,7 @@ mode = os.environ.get("MODE", "step")
 NA = int(os.environ.get("N", "10"))
 table = np.load(os.path.join(os.path.dirname(nat.HERE), "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % NA]
 sim = core.BatchedSim(core.make_params(E, NA))
-sim.set_plugins(nat.POL_RVO)
+sim.set_plugins(getattr(nat, os.environ.get("POLICY", "POL_RVO")))
 sim.set_fixture_table(table)
 sim.reset_from_table()
 lib = nat.lib()

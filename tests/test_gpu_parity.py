@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI, libcagpu.so) against the CPU oracle and the golden vectors
 recorded from the unmodified reference.  Bars (BASELINE.json north_star): collision / done masks bit-exact,
 positions / observations within 1e-5."""
+import ctypes
 import os
 
 import numpy as np
@@ -697,6 +698,95 @@ def test_ga3c_balanced_tile_heights_cover_every_row(live_rows):
     g.ga3c(ext2)
     torch.cuda.synchronize()
     assert np.array_equal(g.ga3c_logits.cpu().numpy(), got) and np.array_equal(ext2.cpu().numpy(), ex)
+
+
+def _ga3c_logits_f64(w, x):
+    """the graph of oracle/ga3c_ref.GA3CNet.logits evaluated in float64 (normalisation in float32 like the graph: it is
+    the network's INPUT): the yardstick for what a float32 evaluation -- numpy's or the kernel's -- loses"""
+    x = np.asarray(x, dtype=np.float32)
+    B = x.shape[0]
+    seq = x[:, 0].astype(np.int32)
+    xn = ((x - w["input_mean"]) / w["input_std"]).astype(np.float32).astype(np.float64)
+    host, others = xn[:, 1:5], xn[:, 5:].reshape(B, 19, 7)
+    W = {k: v.astype(np.float64) for k, v in w.items()}
+    sg = lambda v: 1.0 / (1.0 + np.exp(-v))
+    h, c = np.zeros((B, 64)), np.zeros((B, 64))
+    for t in range(19):
+        z = np.concatenate([others[:, t], h], axis=1) @ W["lstm_kernel"] + W["lstm_bias"]
+        i, j, f, o = np.split(z, 4, axis=1)
+        cn = sg(f + 1.0) * c + sg(i) * np.tanh(j)
+        hn = sg(o) * np.tanh(cn)
+        live = (t < seq)[:, None]
+        c, h = np.where(live, cn, c), np.where(live, hn, h)
+    a = np.concatenate([host, h], axis=1)
+    for n in ("layer1", "layer2", "fc1"):
+        a = np.maximum(a @ W[n + "_kernel"] + W[n + "_bias"], 0)
+    return a @ W["logits_p_kernel"] + W["logits_p_bias"]
+
+
+def test_ga3c_split_operand_network_is_float32_accurate():
+    """The kernel multiplies float32 operands as three bf16 planes each (six of the nine plane products): its logits must
+    sit as close to a float64 evaluation of the graph as numpy's float32 evaluation does (same order of magnitude: both are
+    float32-accumulated), far inside the parity bar -- i.e. the split is a float32-class product, not a bf16 one"""
+    nat, core, orc = _mods()
+    from oracle.ga3c_ref import GA3CNet
+    E, N, K = 256, 16, 19
+    rng = np.random.default_rng(77)
+    g = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=1))
+    g.set_plugins(nat.POL_GA3C_CADRL)
+    obs = _ga3c_obs(rng, E, N, K)
+    g.obs.copy_(torch.from_numpy(obs))
+    g.load_ga3c(keep_logits=True)
+    g.ga3c(torch.zeros((E, N, 2), dtype=torch.float64, device=g.device))
+    torch.cuda.synchronize()
+    got = g.ga3c_logits.cpu().numpy().reshape(E * N, 11).astype(np.float64)
+    net = GA3CNet()
+    x = net.policy_vector(obs.reshape(E * N, -1))
+    ref64 = _ga3c_logits_f64(net.w, x)
+    ref32 = net.logits(x).astype(np.float64)
+    err_gpu, err_np = np.abs(got - ref64), np.abs(ref32 - ref64)
+    scale = np.abs(ref64).max()
+    print("logits up to %.2f: |gpu - f64| max %.3g mean %.3g; |numpy f32 - f64| max %.3g mean %.3g" % (
+        scale, err_gpu.max(), err_gpu.mean(), err_np.max(), err_np.mean()))
+    # measured: logits up to 64; |gpu - f64| max 3.1e-5 mean 1.65e-6; |numpy f32 - f64| max 2.0e-5 mean 1.33e-6
+    assert err_gpu.max() < 3 * err_np.max() and err_gpu.mean() < 2 * err_np.mean()
+    # (a bf16-precision product would be off by ~1e-1 here: four orders of magnitude above the bound)
+
+
+def test_ga3c_pack_is_an_exact_split_and_required():
+    """cagpu_ga3c_pack: every packed weight is hi + mid + lo EXACTLY (three bf16 planes, fragment order of
+    csrc/cagpu_ga3c.inc), rows past a matrix's K are zero; cagpu_ga3c refuses a CaNet without it"""
+    nat, core, orc = _mods()
+    g = core.BatchedSim(core.make_params(4, 3, max_obs=19, sort_mode=1))
+    g.set_plugins(nat.POL_GA3C_CADRL)
+    g.load_ga3c()
+    torch.cuda.synchronize()
+    ts = g._net_tensors
+    pk = ts["packed"].cpu().numpy().view(np.uint16).reshape(-1, 3, 64, 8)     # [(kb, cb), plane, lane, e]
+    assert pk.shape[0] * 3 * 64 * 16 == int(g.lib.cagpu_ga3c_packed_bytes())
+    planes = (pk.astype(np.uint32) << 16).view(np.float32)                     # bf16 -> float32, exact
+    at = 0
+    for name, row0, nkb in (("lstm_kernel", 7, 2), ("layer1_kernel", 4, 2), ("layer2_kernel", 0, 8), ("fc1_kernel", 0, 8)):
+        w = ts[name].cpu().numpy()
+        blk = planes[at:at + nkb * 16].reshape(nkb, 16, 3, 64, 8)
+        at += nkb * 16
+        lane = np.arange(64)
+        m, q = lane & 15, lane >> 4
+        for kb in range(nkb):
+            for cb in range(16):
+                k = row0 + kb * 32 + 8 * q[:, None] + np.arange(8)[None, :]    # [lane, e]
+                want = w[k, (cb * 16 + m)[:, None]]
+                p3 = blk[kb, cb]
+                total = (p3[0].astype(np.float64) + p3[1] + p3[2]).astype(np.float32)
+                assert np.array_equal(total, want), (name, kb, cb)
+                assert np.all(np.abs(p3[1]) <= np.abs(p3[0]) * 2.0 ** -7 + 1e-45) and np.all(np.abs(p3[2]) <= np.abs(p3[0]) * 2.0 ** -15 + 1e-45)
+    assert at == planes.shape[0]
+    g._net.packed = None
+    with pytest.raises(nat.CagpuError, match="packed"):
+        g.ga3c(torch.zeros((4, 3, 2), dtype=torch.float64, device=g.device))
+    bad = nat.CaNet()
+    assert g.lib.cagpu_ga3c_pack(ctypes.byref(bad), ts["packed"].data_ptr(), ts["packed"].numel(), None) == nat.CA_EINVAL
+    assert g.lib.cagpu_ga3c_pack(ctypes.byref(g._nets[0][0]), ts["packed"].data_ptr(), 16, None) == nat.CA_EINVAL
 
 
 def test_ga3c_needs_loaded_network():
