@@ -1,10 +1,11 @@
 #!/bin/bash
-# PMC passes over ga3c_kernel alone (scratch/ga3c_loop.py: 20 launches at ~80 k live rows = three full rounds of tiles)
+# PMC passes over ga3c_kernel (scratch/ga3c_loop.py: 150 steps of the config-3 workload, then 40 back-to-back launches at the
+# steady state's ~30 k live rows; the means below run over all 190 dispatches)
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 O=$R/gpurun_out/ga3c_pmc
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-P="python $R/scratch/ga3c_loop.py"
+P="env WARM=150 N=40 python $R/scratch/ga3c_loop.py"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $P > $O/stats.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/p1 -- $P > $O/p1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS --output-format csv -d $O/p2 -- $P > $O/p2.log 2>&1
@@ -23,6 +24,4 @@ for d in ("p1", "p2", "p3"):
 for f in glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         print(r["Name"][:60], r["Calls"], r["AverageNs"])
-for d in ("p1", "p2", "p3"):
-    os.system("tail -n 3 %s/%s.log" % (O, d))
 PY

@@ -40,5 +40,7 @@ find $O -name '*agent_info.csv' -delete
 # keep the merged output small: the kernel-trace csv of the long runs is not needed (the stats csv is)
 find $O -name '*kernel_trace.csv' -size +8M -delete
 cd $R
+bash scratch/ga3c_pmc.sh > $O/ga3c_pmc.txt 2>&1
+cd $R
 python profiles/summarize.py $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq $O/prof_sq2 $O/prof_sq_rollout $O/prof_ga3c $O/prof_crowd > $O/summary.md 2>&1
 du -sh $O
