@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <type_traits>
 
 #include "cagpu.h"
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   double* tmat = gmat + static_cast<size_t>(N) * CS;     // [N][CS] time to impact (time_to_impact sorting only)
   int* kmat = reinterpret_cast<int*>(tmat + static_cast<size_t>(has_tti ? N : 0) * CS);  // [N][CS] sort key
   float* d2mat = reinterpret_cast<float*>(kmat + static_cast<size_t>(N) * CS);           // [N][CS] dist_2_other
-  uint8_t* rmat = reinterpret_cast<uint8_t*>(d2mat + static_cast<size_t>(N) * CS);       // [N][CS] rank (<= N <= 64)
+  // (one spare byte per pair behind d2mat: the first-pass ranks closest_last's second pass read until round 4)
   float* sh_obs = reinterpret_cast<float*>(un + align16(static_cast<size_t>(CS) * N * ((has_tti ? 3 : 2) * 8 + 9)));
 
   // ---- load my agent
@@ -1273,7 +1274,7 @@ LP1_UNROLL
         const int eb = __mul24(div_small<NC>(ag, inv_n), N), aa = ag - eb;
         const int kj = kmat[j * CS + ag];
         const double oj = omat[j * CS + ag];
-        int rank = 0, cnt = 0;
+        int rank = 0, cnt = 0, lt = 0, same = 0;  // lt / same: candidates in closer buckets / in this one (itself included)
         if (p.sort_mode == CA_SORT_TIME_TO_IMPACT) {  // key (-tti, -dist, p_orth), sensor :36-38
           const bool vj = kj != KEY_NONE;
           const double tj = vj ? tmat[j * CS + ag] : 0.0;
@@ -1292,12 +1293,12 @@ LP1_UNROLL
           // Pass 1 ranks by the distance bucket alone (one 4-byte key per candidate, branch-free).  Two candidates of
           // an agent share a 1 cm bucket in a few per cent of the rows only: the (p_orth, index) tie-break -- an 8-byte
           // load and two float64 compares per candidate -- runs as a second pass in the waves that hold such a row.
-          int same = 0;
           for_n<8>(N, [&](const int q) {
             const int kq = kmat[q * CS + ag];
             rank += static_cast<int>(kq < kj);
             same += static_cast<int>(kq == kj);
           });
+          lt = rank;
           if (__any(same > 1)) {  // (a key always equals itself)
             for_n<8>(N, [&](const int q) {
               const int kq = kmat[q * CS + ag];
@@ -1321,16 +1322,21 @@ LP1_UNROLL
             z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = z[6] = 0.f;
           }
         const bool kept = (j != aa) && (kj != KEY_NONE) && (rank < keep);
-        if (p.sort_mode == CA_SORT_CLOSEST_LAST) {
-          rmat[j * CS + ag] = static_cast<uint8_t>(kept ? rank : N);
-          continue;
-        }
         if (!kept) continue;
+        // closest_last re-sorts the KEPT ones by (-key, p_orth), stable (sensor :41-43): the buckets in reverse, the order
+        // inside a bucket as in the first pass.  No second ranking pass is needed for that: the kept ones of farther buckets
+        // are keep - (closer ones, all kept) - (this bucket's kept ones = min(same, keep - lt)), and the place inside the
+        // bucket is rank - lt.
+        int slot = rank;
+        if (p.sort_mode == CA_SORT_CLOSEST_LAST) {
+          const int room = keep - lt;
+          slot = room - (same < room ? same : room) + (rank - lt);
+        }
         const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
         const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
         const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
         const double rx = ox - hx, ry = oy - hy;
-        float* o7 = row + 6 + 7 * rank;
+        float* o7 = row + 6 + 7 * slot;
         o7[0] = static_cast<float>(rx * prx + ry * pry);
         o7[1] = static_cast<float>(rx * (-pry) + ry * prx);
         o7[2] = static_cast<float>(ovx * prx + ovy * pry);
@@ -1338,40 +1344,6 @@ LP1_UNROLL
         o7[4] = static_cast<float>(orad);
         o7[5] = static_cast<float>(hr + orad);
         o7[6] = d2mat[j * CS + ag];
-      }
-      if (p.sort_mode == CA_SORT_CLOSEST_LAST) {  // re-sort the kept ones by (-key, p_orth), stable (sensor :41-43)
-        WG_SYNC();
-        FOR_PAIR_ITEMS(w) {
-          const int ag = div_small<NC>(w, inv_n);
-          const int j = w - __mul24(ag, N);
-          if (!sh_sense[ag]) continue;
-          const int rank = rmat[j * CS + ag];
-          if (rank >= N) continue;
-          const int eb = __mul24(div_small<NC>(ag, inv_n), N);
-          const int kj = kmat[j * CS + ag];
-          const double oj = omat[j * CS + ag];
-          int r2 = 0;
-          for_n<8>(N, [&](const int q) {
-            const int rq = rmat[q * CS + ag];
-            const int kq = kmat[q * CS + ag];
-            const double oq = omat[q * CS + ag];
-            const int lo = static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(rq < rank));
-            r2 += static_cast<int>(rq < N) & (static_cast<int>(kq > kj) | (static_cast<int>(kq == kj) & lo));
-          });
-          float* row = (STAGE ? sh_obs : obs_tile) + __mul24(ag, W);
-          const double hx = sh_px[ag], hy = sh_py[ag], hr = sh_rad[ag], prx = sh_prx[ag], pry = sh_pry[ag];
-          const double ox = sh_px[eb + j], oy = sh_py[eb + j], orad = sh_rad[eb + j];
-          const double ovx = sh_vx[eb + j], ovy = sh_vy[eb + j];
-          const double rx = ox - hx, ry = oy - hy;
-          float* o7 = row + 6 + 7 * r2;
-          o7[0] = static_cast<float>(rx * prx + ry * pry);
-          o7[1] = static_cast<float>(rx * (-pry) + ry * prx);
-          o7[2] = static_cast<float>(ovx * prx + ovy * pry);
-          o7[3] = static_cast<float>(ovx * (-pry) + ovy * prx);
-          o7[4] = static_cast<float>(orad);
-          o7[5] = static_cast<float>(hr + orad);
-          o7[6] = d2mat[j * CS + ag];
-        }
       }
       // ---- A3 (wave 0, while the other waves finish the pair items of P4): rewards + collision flag (env.py:394-456),
       // observation scalars
@@ -2107,13 +2079,13 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   k.rows = net->rows_scratch;
   if (k.rows) {
     if (k.B >= (1L << 31)) return fail(CA_EUNSUPPORTED, "cagpu_ga3c: more than 2^31 agents with rows_scratch%s");
-    // the packing's two counters (slots reserved so far, workgroups arrived) start from zero whatever an aborted earlier
-    // launch or a caller's uninitialised scratch left there; rows_scratch must hold num_envs * num_agents + 3 words
-    if (hipMemsetAsync(net->rows_scratch + k.B + 1, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess)
-      return fail(CA_ELAUNCH, "cagpu_ga3c: clearing the counters of rows_scratch failed (it must hold num_envs * num_agents + 3 int32 words)%s");
+    // the packing's two counters are tagged with this call's epoch (compact_kernel): nothing to clear, whatever an earlier
+    // launch or the caller's allocation left in the scratch; rows_scratch must hold num_envs * num_agents + 6 words
+    static std::atomic<uint32_t> epoch_source{static_cast<uint32_t>(std::chrono::steady_clock::now().time_since_epoch().count())};
+    const uint32_t epoch = epoch_source.fetch_add(1, std::memory_order_relaxed);
     hipLaunchKernelGGL(ga3c::compact_kernel, dim3(static_cast<unsigned>((k.B + 4 * ga3c::CP_NT - 1) / (4 * ga3c::CP_NT))),
                        dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch, net->agent_net,
-                       net->net_index);
+                       net->net_index, epoch);
   }
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
   static thread_local bool lds_raised[16] = {false};

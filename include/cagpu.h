@@ -224,8 +224,9 @@ typedef struct CaNet {
   const float *fc1_kernel, *fc1_bias;       /* fullyconnected1/{kernel [256,256], bias}                               */
   const float *logits_kernel, *logits_bias; /* logits_p/{kernel [256,11], bias [11]}                                  */
   const float *input_mean, *input_std;      /* graph constants `Const`, `Const_1` [138] (= config.py:93-149)          */
-  /* Scratch for cagpu_ga3c, device int32 [num_envs * num_agents + 3] (the library clears the two counter words behind the
-   * list at the start of every call; the order of the packed rows across workgroups is unspecified), or NULL.  With it the agents that need an action
+  /* Scratch for cagpu_ga3c, device int32 [num_envs * num_agents + 6] (the list, its count at [num_envs * num_agents], two
+   * 64-bit counters behind it that are tagged with the call's epoch: the scratch needs NO initialisation and nothing an earlier
+   * or aborted call left in it matters; the order of the packed rows across workgroups is unspecified), or NULL.  With it the agents that need an action
    * this step (GA3C-CADRL policy, not done: collision_avoidance_env.py:310-312 queries no others) are packed first and
    * only their rows are evaluated -- in steady state about half of the agents of an evaluation batch are done and wait
    * for their env's game over.  NULL: every 64-agent tile that holds at least one such agent is evaluated whole. */

@@ -650,6 +650,15 @@ def test_ga3c_logits_and_actions_vs_numpy_network(E, N, K):
         assert np.array_equal(ex[live][:, 0], np.argmax(got[live], axis=1))      # first maximum, like np.argmax
     # the packed list holds exactly the live rows; without it (CaNet.rows_scratch = NULL: whole tiles) the same bits
     assert g.ga3c_rows() == int(live.sum())
+    # the scratch needs no initialisation: garbage in it (list, count and the two tagged counters) changes nothing
+    sc = g._net_tensors["rows_scratch"]
+    sc.copy_(torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, size=sc.numel(), dtype=np.int64).astype(np.int32)))
+    g.ga3c_logits.fill_(-777.0)
+    ext1 = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
+    g.ga3c(ext1)
+    torch.cuda.synchronize()
+    assert g.ga3c_rows() == int(live.sum())
+    assert np.array_equal(g.ga3c_logits.cpu().numpy(), got) and np.array_equal(ext1.cpu().numpy(), ex)
     g._net.rows_scratch = None
     g.ga3c_logits.fill_(-777.0)
     ext2 = torch.full((E, N, 2), -7.0, dtype=torch.float64, device=g.device)
