@@ -798,6 +798,23 @@ def test_ga3c_pack_is_an_exact_split_and_required():
     assert g.lib.cagpu_ga3c_pack(ctypes.byref(g._nets[0][0]), ts["packed"].data_ptr(), 16, None) == nat.CA_EINVAL
 
 
+def test_ga3c_with_nothing_alive_touches_nothing():
+    """every GA3C-CADRL agent done (or none in the batch): the packed list is empty, every workgroup of the network launch
+    leaves at once, ext_actions / logits keep what they held"""
+    nat, core, orc = _mods()
+    for pol in (nat.POL_GA3C_CADRL, nat.POL_RVO):
+        g = core.BatchedSim(core.make_params(300, 7, max_obs=19, sort_mode=1))
+        g.set_plugins(pol)
+        g.state["flags"] |= nat.DONE
+        g.load_ga3c(keep_logits=True)
+        g.ga3c_logits.fill_(-777.0)
+        ext = torch.full((300, 7, 2), -7.0, dtype=torch.float64, device=g.device)
+        g.ga3c(ext)
+        torch.cuda.synchronize()
+        assert g.ga3c_rows() == 0
+        assert bool((ext == -7.0).all()) and bool((g.ga3c_logits == -777.0).all())
+
+
 def test_ga3c_needs_loaded_network():
     nat, core, orc = _mods()
     g = core.BatchedSim(core.make_params(2, 3, max_obs=19))
