@@ -1290,22 +1290,28 @@ LP1_UNROLL
             cnt += static_cast<int>(vq);
           });
         } else {
-          // Pass 1 ranks by the distance bucket alone (one 4-byte key per candidate, branch-free).  Two candidates of
-          // an agent share a 1 cm bucket in a few per cent of the rows only: the (p_orth, index) tie-break -- an 8-byte
-          // load and two float64 compares per candidate -- runs as a second pass in the waves that hold such a row.
+          // Pass 1 ranks by the distance bucket alone (one 4-byte key per candidate, branch-free) and notes WHICH candidates
+          // share this one's 1 cm bucket.  The (p_orth, index) tie-break -- an 8-byte load and two float64 compares -- then
+          // visits only those: a lane pops the set bits of its own mask, the wave loops while any lane has one left (one or
+          // two trips).  Walking all N candidates again whenever some lane of the wave held a tie -- in a dense crowd
+          // always -- was the larger half of this phase at N = 50.
+          unsigned long long eq = 0ull;
           for_n<8>(N, [&](const int q) {
             const int kq = kmat[q * CS + ag];
             rank += static_cast<int>(kq < kj);
-            same += static_cast<int>(kq == kj);
+            eq |= (kq == kj) ? (1ull << q) : 0ull;
           });
+          same = __popcll(eq);  // (a key always equals itself)
           lt = rank;
-          if (__any(same > 1)) {  // (a key always equals itself)
-            for_n<8>(N, [&](const int q) {
-              const int kq = kmat[q * CS + ag];
+          eq &= ~(1ull << j);
+          if (kj == KEY_NONE) eq = 0ull;  // (not a candidate: its rank is never used)
+          while (__any(eq != 0ull)) {
+            if (eq != 0ull) {
+              const int q = __ffsll(static_cast<long long>(eq)) - 1;
+              eq &= eq - 1ull;
               const double oq = omat[q * CS + ag];
-              rank += static_cast<int>(kq == kj) &
-                      (static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j)));
-            });
+              rank += static_cast<int>(oq < oj) | (static_cast<int>(oq == oj) & static_cast<int>(q < j));
+            }
           }
           if (p.sensing_horizon < INFINITY || p.ragged) {
             for_n<8>(N, [&](const int q) { cnt += static_cast<int>(kmat[q * CS + ag] != KEY_NONE); });
