@@ -1295,12 +1295,30 @@ LP1_UNROLL
           // visits only those: a lane pops the set bits of its own mask, the wave loops while any lane has one left (one or
           // two trips).  Walking all N candidates again whenever some lane of the wave held a tie -- in a dense crowd
           // always -- was the larger half of this phase at N = 50.
+          // (the mask is gathered eight candidates at a time as m8 = 2 m8 + (kq == kj): a compare and an add-with-carry per
+          // candidate like the rank itself, bit-reversed and shifted into place once per block -- a 64-bit shift by a
+          // run-time q per candidate doubled the cost of this loop at N = 50)
           unsigned long long eq = 0ull;
-          for_n<8>(N, [&](const int q) {
-            const int kq = kmat[q * CS + ag];
-            rank += static_cast<int>(kq < kj);
-            eq |= (kq == kj) ? (1ull << q) : 0ull;
-          });
+          {
+            int q0 = 0;
+            for (; q0 + 8 <= N; q0 += 8) {
+              unsigned m8 = 0u;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int kq = kmat[(q0 + u) * CS + ag];
+                rank += static_cast<int>(kq < kj);
+                m8 = m8 + m8 + static_cast<unsigned>(kq == kj);
+              }
+              eq |= static_cast<unsigned long long>(__brev(m8) >> 24) << q0;  // (candidate q0 + u sits at bit 7 - u of m8)
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+              if (q0 + u < N) {
+                const int kq = kmat[(q0 + u) * CS + ag];
+                rank += static_cast<int>(kq < kj);
+                eq |= (kq == kj) ? (1ull << (q0 + u)) : 0ull;
+              }
+          }
           same = __popcll(eq);  // (a key always equals itself)
           lt = rank;
           eq &= ~(1ull << j);
