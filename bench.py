@@ -4,10 +4,15 @@
 Metric (BASELINE.json): agent-steps/sec at 4096 envs x 10 agents, RVOPolicy (ORCA) + UnicycleDynamics +
 OtherAgentsStatesSensor (K=9, closest_first), EvaluateConfig constants (DT=0.1, MAX_TIME_RATIO=8), fixture
 cases 10_agents_500_cases with deterministic auto-reset.  One "step" = one `env.step(None)` of every env of the
-shard = one cagpu_step launch through the C ABI.  Weak scaling: every GPU owns 4096 envs (config 4 = 8 x 4096);
-the only collective is one RCCL all-reduce of the 8 episode counters.
+shard, every step's observations / rewards / done flags handed to the caller.  Default launch mode "lookahead": the
+product path of `CollisionAvoidanceEnv.step(None)` -- the next L steps computed in ONE launch of the fused n-step kernel
+(cagpu_rollout_ring through the C ABI) and served slot by slot (core.BatchedSim.step_lookahead; bit-identical to one
+launch per step, tests/test_gpu_ring.py); L = the largest divisor of --steps up to 64, so a timed block of K steps is
+exactly K / L launches and nothing is computed that is not counted.  `--mode step` = one cagpu_step launch per step
+(what a caller with external actions gets), reported beside the headline as `single_launch`.  Weak scaling: every GPU
+owns 4096 envs (config 4 = 8 x 4096); the only collective is one RCCL all-reduce of the 8 episode counters.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout] [--workload rvo10|ga3c20|crowd50_laser]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode lookahead|step|graph|rollout] [--workload rvo10|ga3c20|crowd50_laser]
 The default workload is the metric's; `ga3c20` (BASELINE config 3: 4096 x 20 GA3C-CADRL agents, network on the fp32
 matrix cores) and `crowd50_laser` (config 5: 4096 x 50 RVO agents + static map + LaserScanSensor) are the "next" rows,
 measured with the same harness and reported with their own roofline (profiles/).
@@ -39,15 +44,28 @@ GA3C_MACS_BF16 = 19 * 64 * 256 + 64 * 256 + 2 * 256 * 256
 GA3C_PLANE_PRODUCTS = 6
 
 
-def measured_traffic_bytes(envs, agents):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, profiles/), if they were
-    taken at this geometry; bench.py itself does not run the profiler."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-        f = os.path.join(REPO, "profiles", name)
-        if os.path.exists(f):
-            d = json.load(open(f))
-            if d.get("envs") == envs and d.get("agents") == agents:
-                return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0, "profiles/" + name
+def _profile_records(stem):
+    """the records of profiles/r*_<stem>.json, newest round first (a file holds one record or a list of them)"""
+    import glob
+    out = []
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s.json" % stem)), reverse=True):
+        d = json.load(open(f))
+        for r in (d if isinstance(d, list) else [d]):
+            out.append((r, "profiles/" + os.path.basename(f)))
+    return out
+
+
+def measured_traffic_bytes(envs, agents, kernel, steps_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate passes, each
+    corrected by the factor the same pass measured on a streaming copy of known size with this kernel's 8-byte-per-lane
+    access shape -- cagpu_debug_copy8; profiles/), if they were taken at this geometry and for this kernel; bench.py itself
+    does not run the profiler.  -> (bytes per launch or None, source or None)"""
+    for d, src in _profile_records("traffic"):
+        if d.get("envs") == envs and d.get("agents") == agents and d.get("kernel", "").split("(")[0] in kernel:
+            if "traffic_bytes_per_step" in d:
+                return d["traffic_bytes_per_step"] * steps_per_launch, src
+            if steps_per_launch == 1:   # (records of rounds 2 - 4: raw counters of single-step launches)
+                return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0, src + " (uncalibrated counters)"
     return None, None
 
 
@@ -131,8 +149,10 @@ def reference_python_rate():
 
 def env_api_rates(E, N, steps, torch, dev):
     """What a drop-in user calls: CollisionAvoidanceEnv(num_envs=E).step(None) through the gym-level API of
-    gym_collision_avoidance_amd.envs (fresh output tensors per step by default; zero_copy=True hands out the persistent
-    buffers).  Host wall clock per step, device idle at start and end."""
+    gym_collision_avoidance_amd.envs.  `lookahead` = the default env (step(None) served from the look-ahead ring, every
+    refill a fresh ring: what step() returned stays the caller's); `single_launch` = lookahead=0 (one launch per step into
+    fresh output tensors); `zero_copy` = lookahead=0 with the persistent device buffers.  Host wall clock per step, device
+    idle at start and end."""
     os.environ.setdefault("GYM_CONFIG_CLASS", "EvaluateConfig")
     out = {}
     try:
@@ -140,11 +160,11 @@ def env_api_rates(E, N, steps, torch, dev):
         from gym_collision_avoidance_amd.envs.collision_avoidance_env import CollisionAvoidanceEnv
         Config.MAX_NUM_AGENTS_IN_ENVIRONMENT = N
         Config.MAX_NUM_OTHER_AGENTS_OBSERVED = N - 1
-        for zc in (False, True):
-            env = CollisionAvoidanceEnv(num_envs=E, device=str(dev), zero_copy=zc)
+        for name, kw in (("lookahead", {}), ("single_launch", {"lookahead": 0}), ("zero_copy", {"zero_copy": True})):
+            env = CollisionAvoidanceEnv(num_envs=E, device=str(dev), **kw)
             env.set_fixture_suite(N)
             env.reset()
-            for _ in range(100):
+            for _ in range(128):
                 env.step(None)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -152,10 +172,13 @@ def env_api_rates(E, N, steps, torch, dev):
                 env.step(None)
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
-            out["zero_copy" if zc else "default"] = {"value": E * N * steps / dt, "unit": "agent-steps/s",
-                                                     "us_per_step": dt / steps * 1e6}
-        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; default = fresh obs / reward / "
-                       "game_over tensors per step, zero_copy = the persistent device buffers" % (E, steps))
+            out[name] = {"value": E * N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6}
+            if name == "lookahead":
+                out[name]["ring"] = env.lookahead
+            del env
+        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; lookahead = the default (ring of "
+                       "CollisionAvoidanceEnv.LOOKAHEAD_DEFAULT steps per launch), single_launch = lookahead=0, fresh obs / reward / "
+                       "game_over tensors per step, zero_copy = the persistent device buffers (one launch per step)" % (E, steps))
     except Exception as e:  # noqa: BLE001 -- an extra must never take the bench line down
         out["error"] = repr(e)
     return out
@@ -251,26 +274,29 @@ def crowd_map():
     return grid
 
 
-def valu_block(E, N, kern_s):
-    """The VALU-issue view of the same launch (the kernel's own analysis says issue-bound): VALU
-    instructions per launch from the committed rocprofv3 PMC pass (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; profiles/) over
-    this run's launch duration, against the device's peak issue rate: 256 CUs x 4 SIMDs x 1 wave-instruction per cycle at
-    2.4 GHz."""
-    for name in ("r04_valu.json", "r03_valu.json"):
-        f = os.path.join(REPO, "profiles", name)
-        if not os.path.exists(f):
+def valu_block(E, N, kernel, step_s):
+    """The VALU-issue view of the same kernel (its own analysis says issue-bound), from the committed
+    rocprofv3 PMC passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU; profiles/) over this run's time per step.  The headline is
+    `valu_busy_frac`: cycles in which a SIMD's VALU was issuing / the cycles of a step (SQ_ACTIVE_INST_VALU counts
+    quad-cycles summed over the device's 1024 SIMDs).  `frac` prices the instruction count against the f32 issue peak of
+    MI355X_MICROARCH.md: a wave64 `v_fma_f32` occupies its SIMD-32 for 2 cycles (float64: 4), i.e. 256 CUs x 4 SIMDs x
+    2.4 GHz / 2 = 1.23e12 wave-instructions/s."""
+    for d, src in _profile_records("valu"):
+        if d.get("envs") != E or d.get("agents") != N or d.get("kernel", "").split("(")[0] not in kernel:
             continue
-        d = json.load(open(f))
-        if d.get("envs") != E or d.get("agents") != N:
-            continue
-        peak = 256 * 4 * 2.4e9
-        out = {"valu_insts_per_launch": d["valu_insts_per_launch"], "valu_insts_per_agent_step": d["valu_insts_per_launch"] / (E * N),
-               "achieved_insts_per_s": d["valu_insts_per_launch"] / kern_s, "peak_insts_per_s": peak,
-               "frac": d["valu_insts_per_launch"] / kern_s / peak, "source": "profiles/" + name,
-               "note": "wave-level VALU instructions; float64 ones issue over two (transcendental: four+) cycles, so the issue "
-                       "pipes are busier than frac says -- valu_busy_frac is the counter that measures that"}
+        per_step = d.get("steps_per_launch", 1)
+        insts = d["valu_insts_per_launch"] / per_step
+        peak = 256 * 4 * 2.4e9 / 2.0
+        out = {"valu_insts_per_step": insts, "valu_insts_per_agent_step": insts / (E * N),
+               "achieved_insts_per_s": insts / step_s, "peak_insts_per_s": peak, "frac": insts / step_s / peak,
+               "source": src,
+               "note": "peak = f32 rate (2 cycles per wave64 instruction on a SIMD-32; float64 instructions take 4, "
+                       "transcendentals more): frac is a lower bound of how busy the issue pipes are -- valu_busy_frac "
+                       "(SQ_ACTIVE_INST_VALU) measures it"}
         if d.get("valu_busy_cycles_per_simd"):
-            out["valu_busy_frac"] = d["valu_busy_cycles_per_simd"] / (kern_s * 2.4e9)
+            busy = d["valu_busy_cycles_per_simd"] / per_step
+            out["valu_busy_frac"] = busy / (step_s * 2.4e9)
+            out["busy_cycles_per_valu_inst"] = busy * 1024.0 / insts
         return out
     return None
 
@@ -303,10 +329,20 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--workload", choices=["rvo10", "ga3c20", "crowd50_laser"], default="rvo10")
-    ap.add_argument("--mode", choices=["step", "graph", "rollout"], default="step",
-                    help="step: one launch per env.step, submitted call by call (the gym-compatible path); graph: the same "
-                         "K launches captured once into a HIP graph and replayed (one launch per env.step, no per-call "
-                         "submission); rollout: all K steps fused in one launch")
+    ap.add_argument("--mode", choices=["lookahead", "step", "graph", "rollout"], default=None,
+                    help="lookahead (default for the RVO workload): env.step(None) served from a ring of L steps computed "
+                         "ahead in one launch of the fused n-step kernel, every step's outputs kept (the product path of "
+                         "CollisionAvoidanceEnv.step(None)); step: one launch per env.step, submitted call by call (what a "
+                         "caller with external actions gets; the default of the ga3c20 / crowd50_laser workloads, which need "
+                         "a second kernel between two steps); graph: the same K launches captured once into a HIP graph and "
+                         "replayed; rollout: all K steps fused in one launch, only the last step's outputs kept")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="ring length L of --mode lookahead; 0: the largest divisor of --steps that is <= 64 (a timed block "
+                         "is then exactly steps / L launches)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: initialise torch.distributed (--backend, default nccl = RCCL) with world_size 1 anyway and "
+                         "run every collective of the N > 1 path (barriers, the MAX all-reduce of the block table, the "
+                         "episode-statistics all-reduce, the all-gather of per-rank times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ga3c-fused", action="store_true",
                     help="ga3c20: cagpu_ga3c computes the observation rows it needs from the state itself (obs = NULL: sensing + "
@@ -341,9 +377,20 @@ def main():
     if world > 1 and not a.share_device and torch.cuda.device_count() < world:
         sys.exit("bench.py: --gpus %d but only %d device(s) visible (one rank per GPU; --share-device is for 1-GPU tests)"
                  % (world, torch.cuda.device_count()))
-    if world > 1:
+    if a.mode is None:
+        a.mode = "lookahead" if a.workload == "rvo10" else "step"
+    if a.mode == "lookahead" and a.workload != "rvo10":
+        sys.exit("bench.py: --mode lookahead needs a workload without work between two steps (rvo10)")
+    dist_on = world > 1 or a.force_dist     # every collective below runs whenever a process group exists
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:   # --force-dist without a launcher: a one-rank group on a free port
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
         if a.share_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -364,9 +411,18 @@ def main():
     off, stride = shard_env_ids(rank, world, E)
 
     graph = {}
+    L = 1
+    if a.mode == "lookahead":
+        L = a.lookahead if a.lookahead > 0 else max(d for d in range(1, 65) if a.steps % d == 0)
+        if a.steps % L:
+            sys.exit("bench.py: --lookahead %d does not divide --steps %d (a timed block must be whole launches)" % (L, a.steps))
+        sim.enable_lookahead(L, fresh=True)
 
     def run(n):
-        if a.mode == "graph" and n in graph:
+        if a.mode == "lookahead":
+            for _ in range(n):
+                sim.step_lookahead()
+        elif a.mode == "graph" and n in graph:
             graph[n].replay()
         elif a.mode == "rollout":
             sim.rollout(n)
@@ -387,8 +443,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     ev1.record()
-    reduce_episode_stats(sim.episode_stats(), world)
-    run(a.warmup)
+    reduce_episode_stats(sim.episode_stats(), world, force=dist_on)
+    chunk = 50 if a.mode in ("step", "graph") else (a.steps if a.mode == "rollout" else L * max(1, 50 // L))
+    run(a.warmup if a.mode != "lookahead" else -(-a.warmup // L) * L)   # (whole rings: a timed block starts at a ring boundary)
     torch.cuda.synchronize(dev)
     if a.mode == "graph":  # capture the launches of K steps (and of the warm-up chunk) once; run() then replays them
         for n in sorted({a.steps, 50}):
@@ -402,7 +459,7 @@ def main():
     gc.disable()
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < a.min_warm_seconds:
-        run(50 if a.mode in ("step", "graph") else a.steps)
+        run(chunk)
         torch.cuda.synchronize(dev)
 
     # ---- timed: a BLOCK is EXACTLY a.steps steps between barrier + synchronize on both sides, nothing else inside.  One
@@ -410,9 +467,9 @@ def main():
     # sampler never sees it -- so the block is repeated back to back until --min-timed-seconds of device time have been
     # measured and the line reports the MEDIAN block (per block: max over ranks); first / min / max are reported beside it.
     def timed_block():
-        if world > 1:
+        if dist_on:
             dist.barrier()
-            run(20 if a.mode == "step" else (50 if a.mode == "graph" else a.steps))   # the barrier idled the device: bring it back before the clock starts
+            run(20 if a.mode == "step" else (50 if a.mode == "graph" else (L if a.mode == "lookahead" else a.steps)))   # the barrier idled the device: bring it back before the clock starts
         torch.cuda.synchronize(dev)
         ev0.record()            # same stream the kernels are launched on (torch's current stream)
         t0 = time.perf_counter()
@@ -426,31 +483,32 @@ def main():
     if a.min_timed_seconds > 0:
         n_blocks = int(min(max(1, a.max_blocks if world == 1 else min(a.max_blocks, 200)),
                            max(1, np.ceil(a.min_timed_seconds / max(blocks[0][1] * 1e-3, 1e-6)))))
-    if world > 1:   # every rank must run the same number of blocks (there is a barrier in each)
+    if dist_on:   # every rank must run the same number of blocks (there is a barrier in each)
         nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
         dist.broadcast(nb, 0)
         n_blocks = int(nb.item())
     for _ in range(n_blocks - 1):
         blocks.append(timed_block())
     gc.enable()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     bt = torch.tensor(blocks, dtype=torch.float64, device=dev)      # [blocks, (wall s, events ms)]
     bt_local = bt.clone()
-    if world > 1:
+    if dist_on:
         dist.all_reduce(bt, op=dist.ReduceOp.MAX)
     walls, gpus = bt[:, 0].cpu().numpy(), bt[:, 1].cpu().numpy()
     mid = int(np.argsort(walls)[len(walls) // 2])                    # the median block (by wall clock)
     wall, gpu_ms = float(walls[mid]), float(gpus[mid])
     gpu_ms_local = float(bt_local[mid, 1].item())
-    stats = reduce_episode_stats(sim.episode_stats(), world)   # the only collective (8 counters), outside the clock
+    kernel_name = nat.lib().cagpu_last_kernel().decode()       # (of the timed launches: episode_stats() below may rewind the ring)
+    stats_local = sim.episode_stats()
+    stats = reduce_episode_stats(stats_local, world, force=dist_on)   # the only collective (8 counters), outside the clock
     torch.cuda.synchronize(dev)
-    kernel_name = nat.lib().cagpu_last_kernel().decode()
     # ---- multi-GPU evidence the driver can read from the JSON line: ranks seen, per-rank device time of the SAME K
     # steps, and the latency of the one collective (the 8-counter all-reduce), measured outside the step clock
     per_rank_ms, allreduce_us = [gpu_ms_local / a.steps], None
     ranks_seen = 1
-    if world > 1:
+    if dist_on:
         mine = torch.tensor([gpu_ms_local / a.steps], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -460,26 +518,34 @@ def main():
         ranks_seen = int(round(float(one.item())))
         probe = sim.episode_stats()
         for _ in range(5):
-            reduce_episode_stats(probe, world)
+            reduce_episode_stats(probe, world, force=True)
         torch.cuda.synchronize(dev)
         dist.barrier()
         t_c = time.perf_counter()
         for _ in range(50):
-            reduce_episode_stats(probe, world)
+            reduce_episode_stats(probe, world, force=True)
         torch.cuda.synchronize(dev)
         allreduce_us = (time.perf_counter() - t_c) / 50 * 1e6
         if ranks_seen != a.gpus:
             sys.exit("bench.py: %d ranks took part, --gpus %d asked for" % (ranks_seen, a.gpus))
+        if world == 1 and not torch.equal(stats, stats_local):
+            sys.exit("bench.py: the one-rank all-reduce changed the episode statistics")
 
     if rank == 0:
         agent_steps = float(world) * E * N * a.steps
         value = agent_steps / wall
-        launches = 1 if a.mode == "rollout" else a.steps
-        bytes_per_launch = algorithmic_bytes_per_agent_step(K) * E * N * (a.steps / launches)
+        launches = 1 if a.mode == "rollout" else a.steps // L
+        steps_per_launch = a.steps // launches
+        bytes_per_launch = algorithmic_bytes_per_agent_step(K) * E * N * steps_per_launch
         kern_s = gpu_ms * 1e-3 / launches          # average launch duration (HIP events over the timed region)
         achieved = bytes_per_launch / kern_s / 1e9
+        traffic, traffic_src = (measured_traffic_bytes(E, N, kernel_name, steps_per_launch)
+                                if a.mode in ("step", "lookahead") else (None, None))
+        total_envs = world * E
+        shape = {(4096, 10): "the metric's size (configs[3] = 8 of these shards)", (1024, 10): "BASELINE configs[1]",
+                 (32768, 10): "BASELINE configs[3] as ONE batch on one GPU"}.get((E, N), "a side configuration")
         out = {
-            "metric": "agent-steps/sec at 4096 envs x 10 agents (RVO)", "value": value, "unit": "agent-steps/s",
+            "metric": "agent-steps/sec at %d envs x %d agents (RVO)" % (E, N), "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
             "event_ms_per_step": gpu_ms / a.steps,   # HIP events around the same K steps (device time only)
             "timed_blocks": {"blocks": len(walls), "steps_per_block": a.steps, "reported": "median block by wall clock",
@@ -488,27 +554,53 @@ def main():
                              "device_seconds_timed": float(gpus.sum()) * 1e-3},
             "suspect": bool(abs(wall * 1e3 - gpu_ms) > 0.2 * gpu_ms),  # host wall clock and device time disagree by > 20 %
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]-shaped at the metric size: %d envs/GPU x %d agents, RVOPolicy(ORCA) + "
-                                   "UnicycleDynamics + OtherAgentsStatesSensor K=%d closest_first, DT=0.1, "
-                                   "fixture 10_agents_500_cases, auto-reset" % (E, N, K),
-                       "envs_per_gpu": E, "agents": N, "launch_mode": a.mode, "parallelism": "env-shard x%d" % world},
+            "config": {"workload": "%d envs/GPU x %d agents (%s; %d envs in all), RVOPolicy(ORCA) + UnicycleDynamics + "
+                                   "OtherAgentsStatesSensor K=%d closest_first, DT=0.1, fixture %d_agents_500_cases, auto-reset; "
+                                   "every step's obs / rewards / done / game_over handed out" % (E, N, shape, total_envs, K, N),
+                       "envs_per_gpu": E, "agents": N, "parallelism": "env-shard x%d" % world,
+                       "launch_mode": ("lookahead-%d" % L) if a.mode == "lookahead" else a.mode,
+                       "launch_mode_note": {
+                           "lookahead": "env.step(None) served from a ring of %d steps computed ahead by ONE launch of the fused "
+                                        "n-step kernel (cagpu_rollout_ring); bit-identical to one launch per step "
+                                        "(tests/test_gpu_ring.py); a timed block of %d steps = %d launches + %d state snapshots"
+                                        % (L, a.steps, launches, launches),
+                           "step": "one cagpu_step launch per env.step",
+                           "graph": "one cagpu_step launch per env.step, replayed from a HIP graph",
+                           "rollout": "cagpu_rollout: all steps in one launch, only the LAST step's outputs are kept"}[a.mode]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic_bytes(E, N)[0] if a.mode == "step" else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command, committed as %s; "
-                                         "not re-measured in this run)" % measured_traffic_bytes(E, N)[1],
+                         "traffic": traffic,
+                         "traffic_unit": ("bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE passes over this kernel, committed as %s "
+                                          "(not re-measured in this run)" % traffic_src) if traffic is not None else
+                                         "no committed counter pass for this geometry / kernel",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": kernel_name, "avg_launch_us": kern_s * 1e6,
+                         "kernel": kernel_name, "avg_launch_us": kern_s * 1e6, "steps_per_launch": steps_per_launch,
+                         "us_per_step": kern_s * 1e6 / steps_per_launch,
                          "algorithmic_bytes_per_agent_step": algorithmic_bytes_per_agent_step(K),
-                         "valu": valu_block(E, N, kern_s) if (a.mode == "step" and a.workload == "rvo10") else None},
+                         "valu": valu_block(E, N, kernel_name, kern_s / steps_per_launch) if a.workload == "rvo10" else None},
             "episode_stats": dict(zip(core.STAT_NAMES, [float(x) for x in stats.cpu().numpy()])),
             "ranks_seen": ranks_seen,
+            "distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist_on else None),
             "per_rank_event_ms_per_step": per_rank_ms,
             "stats_allreduce_us": allreduce_us,   # the ONLY collective (RCCL all-reduce of 8 float64 counters), off the step path
         }
         if a.workload != "rvo10":
             extra_workload(out, a, sim, core, E, N, K, dev, torch)
-        if world == 1 and a.mode == "step" and a.workload == "rvo10" and not a.no_extras:
+        extras = world == 1 and a.mode in ("step", "lookahead") and a.workload == "rvo10" and not a.no_extras
+        if extras and a.mode == "lookahead":
+            # beside the headline: the same workload one cagpu_step launch per step (what a caller with external actions gets)
+            n1 = max(a.steps, 500)
+            sim.sync()
+            for _ in range(50):
+                sim.step()
+            s1 = _time_launches(lambda: sim.step(), n1, torch, dev)
+            out["single_launch"] = {"value": E * N / s1, "unit": "agent-steps/s", "us_per_step": s1 * 1e6, "launches": n1,
+                                    "kernel": nat.lib().cagpu_last_kernel().decode(),
+                                    "roofline_frac": algorithmic_bytes_per_agent_step(K) * E * N / s1 / 1e9 / HBM_PEAK_GBS,
+                                    "note": "one cagpu_step launch per env.step(None) (HIP events over %d back-to-back launches): a "
+                                            "launch ends with its slowest workgroup, the fused n-step kernel of the headline runs "
+                                            "at the mean" % n1}
+        if extras:
             # extra: the same K steps fused into ONE cagpu_rollout launch (env_utils.run_episode's loop on the device)
             torch.cuda.synchronize(dev)
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -521,7 +613,7 @@ def main():
                               "ms_per_step": rms / a.steps, "launches": 1,
                               "note": "same workload, %d steps in one launch (state stays in registers/LDS between "
                                       "steps; observations, rewards and done flags are still written every step)" % a.steps}
-        if world == 1 and a.mode == "step" and a.workload == "rvo10" and E % 2 == 0 and not a.no_extras:
+        if extras and a.mode == "step" and E % 2 == 0:
             # extra: the same batch as two half-batches on two HIP streams (envs are independent): the tail of one
             # launch -- a launch ends with its slowest workgroup -- overlaps with the body of the other
             halves, streams = [], [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -566,12 +658,12 @@ def main():
                                           "two branches of one HIP graph (the ramp-up and the tail of one chain's launch "
                                           "overlap with the body of the other's); not the headline: per-launch durations "
                                           "overlap, so the roofline above is quoted for the single-chain launch" % (E // 2, nrep)}
-        if world == 1 and a.mode == "step" and a.workload == "rvo10" and not a.no_extras:
-            out["env_api"] = env_api_rates(E, N, min(a.steps, 1000), torch, dev)
+        if extras:
+            out["env_api"] = env_api_rates(E, N, min(max(a.steps, 640), 1280), torch, dev)
         if world == 1 and not a.no_cpu_baseline and a.workload == "rvo10":
             out["cpu_baseline"] = cpu_baseline(N, K)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 9   # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 10  # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -74,7 +74,7 @@ class CaNet(C.Structure):
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
            "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes",
-           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack")
+           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack", "cagpu_rollout_ring", "cagpu_debug_copy8")
 
 _lib = None
 
@@ -102,6 +102,8 @@ def lib():
     L.cagpu_reset.argtypes = [PP, PS, PO, _P, _P, _P, _P]
     L.cagpu_step.argtypes = [PP, PS, PO, _P, PA, _P]
     L.cagpu_rollout.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
+    L.cagpu_rollout_ring.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
+    L.cagpu_debug_copy8.argtypes = [C.c_int64, _P, _P, _P]
     L.cagpu_step_map.argtypes = [PP, PS, PO, _P, PA, C.POINTER(CaMap), _P]
     L.cagpu_laserscan.argtypes = [PP, PS, C.POINTER(CaMap), C.POINTER(CaScan), _P]
     L.cagpu_observe.argtypes = [PP, PS, PO, _P]

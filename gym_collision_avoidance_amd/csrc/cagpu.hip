@@ -68,6 +68,10 @@ struct KArgs {
   int32_t tile_envs;  // envs per workgroup (<= ROW / num_agents)
   int32_t col_stride; // columns of the per-(agent, slot) LDS tiles: ROW, or N for single-env tiles (N > 32)
   double inv_rvo_dt;  // 1 / p.rvo_dt (RVOPolicy.py:106), divided once on the host
+  // cagpu_rollout_ring: step t of the launch writes its outputs to slot t of the caller's ring -- element strides between
+  // the slots of the observation block (E N W), of the per-agent outputs (E N; x 2 for the action pairs) and of game_over (E);
+  // all 0 everywhere else (every step writes the same buffers)
+  int64_t ring_obs, ring_agent, ring_env;
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -621,7 +625,9 @@ __device__ __forceinline__ void reset_lane(Lane& r, const double* c, const bool 
 }
 
 template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int TE = 0>
-__global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) {  // n-step: <= 128 VGPRs (4 waves / SIMD)
+// n-step: <= 128 VGPRs (four 4-wave workgroups per CU) -- except N = 20, whose single-step form already needs 172 (two
+// workgroups per CU either way): held to 128 its n-step form spilled ~200 VGPRs to scratch around the step loop
+__global__ __launch_bounds__(NT, MULTI ? (NC == 20 ? 2 : 4) : 1) void ca_kernel(const KArgs k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const CaParams& p = k.p;
   const int N = NC ? NC : p.num_agents;  // NC > 0: compile-time agent count (loops unroll, divisions fold)
@@ -644,7 +650,8 @@ __global__ __launch_bounds__(NT, MULTI ? 4 : 1) void ca_kernel(const KArgs k) { 
   const int ebase = active ? le * N : 0;
   const long i = e * N + a;
   const long tile_base = env0 * N;
-  float* const obs_tile = k.o.obs + tile_base * (6 + 7 * p.max_obs);  // the tile's observation rows (uniform: scalar arithmetic)
+  float* obs_tile = k.o.obs + tile_base * (6 + 7 * p.max_obs);  // the tile's observation rows (uniform: scalar arithmetic)
+  long ring_a = 0, ring_e = 0;  // n-step kernel: this step's slot of the caller's output ring (cagpu_rollout_ring), in elements
   long tile_cnt = static_cast<long>(p.num_envs) * N - tile_base;
   if (tile_cnt > tile_n) tile_cnt = tile_n;
 
@@ -1095,9 +1102,9 @@ LP1_UNROLL
         }
         TICK(4);
         const float a0f = static_cast<float>(spd), a1f = static_cast<float>(dh);  // float32 `all_actions`
-        if (active && k.o.actions) reinterpret_cast<float2*>(k.o.actions)[i] = make_float2(a0f, a1f);
+        if (active && k.o.actions) reinterpret_cast<float2*>(k.o.actions)[i + ring_a] = make_float2(a0f, a1f);
         if (active && k.o.orca_vel)  // parity hook: the velocity rvo2 chose for this agent (RVOPolicy.py:93), 0 if not queried
-          reinterpret_cast<float2*>(k.o.orca_vel)[i] = rvo ? make_float2(v_orca.x, v_orca.y) : make_float2(0.f, 0.f);
+          reinterpret_cast<float2*>(k.o.orca_vel)[i + ring_a] = rvo ? make_float2(v_orca.x, v_orca.y) : make_float2(0.f, 0.f);
         if (active) {
           if (r.flags & (CA_AT_GOAL | CA_OUT_OF_TIME | CA_IN_COLLISION)) {
             if (r.flags & CA_AT_GOAL) r.flags |= CA_WAS_AT_GOAL;
@@ -1442,9 +1449,9 @@ LP1_UNROLL
           bool over = all_done;
           if (p.game_over_mode == CA_OVER_AGENT0) over = (sh_flag[ebase] & CA_DONE) != 0;
           else if (p.game_over_mode == CA_OVER_LEARNING_DONE) over = all_learning_done;
-          k.o.rewards[i] = reward;
-          k.o.done[i] = static_cast<uint8_t>((r.flags & CA_DONE) != 0);
-          if (a == 0) k.o.game_over[e] = static_cast<uint8_t>(over);
+          k.o.rewards[i + ring_a] = reward;
+          k.o.done[i + ring_a] = static_cast<uint8_t>((r.flags & CA_DONE) != 0);
+          if (a == 0) k.o.game_over[e + ring_e] = static_cast<uint8_t>(over);
           if (over && k.table) {
             if (a == 0) {  // experiments/src/env_utils.py:56-87 reduced to counters, summed in agent order
               double tot_r = 0.0, ttg = 0.0, extra = 0.0;
@@ -1503,7 +1510,7 @@ LP1_UNROLL
             if (col == 0)  // (is_learning comes from the live flags; the row of an absent slot is all zeros: radius 0)
               v = ((sh_flag[le2 * N + a2] & CA_IS_LEARNING) && !(p.ragged && !(src[q + 5] > 0.f))) ? 1.f : 0.f;
             if (STAGE) sh_obs[base + q] = v;
-            else k.o.obs[tile_base * W + base + q] = v;
+            else obs_tile[base + q] = v;
           }
         }
         WG_SYNC();
@@ -1512,7 +1519,7 @@ LP1_UNROLL
         // ---- the tile's observation block leaves LDS as one contiguous, coalesced copy
         if (STAGE && !AB(128)) {
           const long total = tile_cnt * W;
-          float* dst = k.o.obs + tile_base * W;
+          float* dst = obs_tile;
           if (k.mode == MODE_RESET && k.reset_mask) {
             for (long q = tid; q < total; q += NT) {
               const long ee = env0 + (q / W) / N;
@@ -1540,7 +1547,12 @@ LP1_UNROLL
   };
   if (MULTI) {
     const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
-    for (int step = 0; step < n_steps; ++step) one_step();
+    for (int step = 0; step < n_steps; ++step) {
+      one_step();
+      obs_tile += k.ring_obs;  // (0 unless the caller keeps every step's outputs: cagpu_rollout_ring)
+      ring_a += k.ring_agent;
+      ring_e += k.ring_env;
+    }
   } else {
     one_step();
   }
@@ -1707,6 +1719,16 @@ const Knobs& knobs() {
 #endif
 }
 
+// n single-step launches in place of one n-step launch: the next launch writes the next slot of the caller's output ring
+void ring_advance(KArgs& k) {
+  k.o.obs += k.ring_obs;
+  k.o.rewards += k.ring_agent;
+  k.o.done += k.ring_agent;
+  k.o.game_over += k.ring_env;
+  if (k.o.actions) k.o.actions += 2 * k.ring_agent;
+  if (k.o.orca_vel) k.o.orca_vel += 2 * k.ring_agent;
+}
+
 template <int NT, bool STAGE, int NC, bool MULTI, bool RO, int TE = 0>
 int launch_main5(const KArgs& k, size_t total, hipStream_t st) {
   // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
@@ -1797,7 +1819,8 @@ int launch_main(const KArgs& k, hipStream_t st) {
   // at once; otherwise n launches of the single-step kernel are faster (136 vs 158 us / step at 32768 envs) and give
   // bit-identical results (envs never interact; tests/test_gpu_parity.py::test_rollout_equals_repeated_steps).
   const long lds_cap = static_cast<long>((160 * 1024) / total);
-  const long fused_resident = (lds_cap < 4 ? lds_cap : 4) * n_cu;
+  const long reg_cap = (N == 20) ? 2 : 4;  // (ca_kernel's __launch_bounds__)
+  const long fused_resident = (lds_cap < reg_cap ? lds_cap : reg_cap) * n_cu;
   if (k.mode == MODE_STEP && k.n_steps > 1 && wgs > fused_resident && !knobs().rollout_fused) {
     KArgs k1 = k;
     k1.n_steps = 1;
@@ -1808,6 +1831,7 @@ int launch_main(const KArgs& k, hipStream_t st) {
       const int rc = stage ? launch_main2<256, true>(k1, total, st) : launch_main2<256, false>(k1, total, st);
 #endif
       if (rc) return rc;
+      ring_advance(k1);
     }
     return CA_OK;
   }
@@ -1899,6 +1923,7 @@ int launch_big(const KArgs& k0, hipStream_t st) {
                        static_cast<unsigned char*>(k.o.workspace), per);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
+    ring_advance(k);
   }
   return CA_OK;
 }
@@ -1981,6 +2006,12 @@ __global__ void debug_libm_kernel(const int n, const int op, const double* a, co
   if (o1) o1[i] = r1;
 }
 
+// cagpu_debug_copy8: a streaming copy with the step kernels' 8-bytes-per-lane access shape (counter calibration)
+__global__ __launch_bounds__(256) void copy8_kernel(const long n, const double* __restrict__ src, double* __restrict__ dst) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -2005,10 +2036,13 @@ int cagpu_reset(const CaParams* p, const CaState* s, const CaOut* o, const doubl
 }
 
 static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const double* ext, const CaAutoReset* ar,
-                     int32_t n_steps, void* stream, const CaMap* map = nullptr) {
+                     int32_t n_steps, void* stream, const CaMap* map = nullptr, const bool ring = false) {
   int rc = check_params(p, s, o);
   if (rc) return rc;
   if (n_steps < 1) return fail(CA_EINVAL, "cagpu: n_steps must be >= 1%s");
+  if ((n_steps > 1 || ring) && (s->rvo_collab || s->rvo_heading_noise || s->ext_state))
+    return fail(CA_EINVAL, "cagpu: CaState.rvo_collab / rvo_heading_noise / ext_state are inputs of ONE step (the caller draws / "
+                           "integrates them per step): not accepted by a multi-step call%s");
   KArgs k;
   std::memset(&k, 0, sizeof(k));
   k.p = *p; k.s = *s; k.o = *o; k.ext = ext;
@@ -2025,6 +2059,11 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
   }
   k.n_steps = n_steps; k.mode = MODE_STEP;
   k.inv_rvo_dt = 1.0 / p->rvo_dt;
+  if (ring) {
+    k.ring_agent = static_cast<int64_t>(p->num_envs) * p->num_agents;
+    k.ring_obs = k.ring_agent * (6 + 7 * p->max_obs);
+    k.ring_env = p->num_envs;
+  }
 #ifdef CAGPU_ABLATE
   if (const char* ab = std::getenv("CAGPU_ABLATE")) k.ablate = std::atoi(ab);
 #endif
@@ -2200,6 +2239,11 @@ int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const dou
   return step_impl(p, s, o, ext_actions, ar, n_steps, stream);
 }
 
+int cagpu_rollout_ring(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,
+                       int32_t n_steps, void* stream) {
+  return step_impl(p, s, o, ext_actions, ar, n_steps, stream, nullptr, true);
+}
+
 int cagpu_plan(const CaParams* p, const CaState* s, void* stream) {
   if (!p || !s) return fail(CA_EINVAL, "cagpu_plan: NULL params/state%s");
   if (p->num_agents > 10) return fail(CA_EUNSUPPORTED, "cagpu_plan: no pipelined step kernel for more than 10 agents per env%s");
@@ -2321,6 +2365,15 @@ int cagpu_debug_libm(int32_t op, int32_t n, const double* a, const double* b, do
   if (e == hipSuccess && out1) e = hipMemcpy(out1, d + 3 * n, sz, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_debug_libm: %s", hipGetErrorString(e));
+  return CA_OK;
+}
+
+int cagpu_debug_copy8(int64_t n, const double* src, double* dst, void* stream) {
+  if (n < 1 || !src || !dst) return fail(CA_EINVAL, "cagpu_debug_copy8: bad arguments%s");
+  hipLaunchKernelGGL(copy8_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<long>(n), src, dst);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
 }
 

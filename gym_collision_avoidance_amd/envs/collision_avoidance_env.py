@@ -58,15 +58,28 @@ class _HostAgent(object):
 class CollisionAvoidanceEnv(Env):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
 
-    def __init__(self, num_envs=1, device="cuda:0", zero_copy=False):
+    LOOKAHEAD_DEFAULT = 32
+
+    def __init__(self, num_envs=1, device="cuda:0", zero_copy=False, lookahead=None):
         """zero_copy (batched mode only): False -- step() / rollout() / reset() return FRESH tensors, like the
         reference's DummyVecEnv returns fresh arrays every step (vec_env.py:120-135): safe to append to a rollout
         buffer or to keep as prev_obs.  True -- they return the simulator's persistent device buffers, which the NEXT
-        launch overwrites in place (no copy; for consumers that read the outputs before stepping again)."""
+        launch overwrites in place (no copy; for consumers that read the outputs before stepping again).
+
+        lookahead (batched mode only): `step(None)` of a batch whose policies are all internal needs nothing from the
+        host (the reference's run_episode passes None until the episode is over, env_utils.py:45-52), so the next
+        `lookahead` steps are computed in ONE launch of the fused n-step kernel (cagpu_rollout_ring) and step(None)
+        hands out one slot of that ring per call -- same results bit for bit, about half the time per step (a fused
+        rollout never waits for the slowest workgroup of a step).  Whatever needs the simulator exactly at the step
+        last handed out -- an action, a custom `dt`, reset(), reading an agent's state, episode_stats() -- rewinds
+        transparently (core.BatchedSim.sync).  None: LOOKAHEAD_DEFAULT unless zero_copy (whose contract is ONE
+        persistent buffer); 0: off (one launch per step)."""
         self.id = 0
         self.num_envs = int(num_envs)
         self.device = device
         self.zero_copy = bool(zero_copy)
+        self.lookahead = (0 if zero_copy else self.LOOKAHEAD_DEFAULT) if lookahead is None else max(0, int(lookahead))
+        self._la_on, self._la_dt_ok = False, True
         self._initialize_rewards()
         self.num_agents = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
         self.dt_nominal = Config.DT
@@ -195,7 +208,19 @@ class CollisionAvoidanceEnv(Env):
         if self._sim is None:
             raise RuntimeError("call reset() before step()")
         sim = self._sim
+        if self._la_on and actions is None and (dt is None or float(dt) == self.dt_nominal):
+            # every policy internal, nothing to do between two steps: one slot of the look-ahead ring (see __init__)
+            if not self._la_dt_ok:   # (a step with another dt came before: it went through sync(), no ring is in flight)
+                sim.p.dt = self.dt_nominal
+                self._la_dt_ok = True
+            self.episode_step_number += 1
+            self._snap = self._obs_np = self._scan_np = None
+            obs, rewards, done, over = sim.step_lookahead()
+            return obs, rewards, over, False, {"which_agents_done": done, "which_agents_learning": self._learning_info}
+        if self._la_on:
+            sim.sync()             # an action / another dt: the simulator has to stand at the step last handed out
         sim.p.dt = self.dt_nominal if dt is None else float(dt)
+        self._la_dt_ok = sim.p.dt == self.dt_nominal
         self.episode_step_number += 1
         ext = self._external_actions(actions)
         sim.step(ext, ext_state=self._ext_state)
@@ -351,7 +376,9 @@ class CollisionAvoidanceEnv(Env):
         variants = []
         for (c_, s_), where in sensor_others.items():   # (a fixture batch / one shared agent list: a slot's pair holds for every env)
             mask = np.zeros((E, N), dtype=bool)
-            shared = self._fixture is not None or per_env is None or any(g is None for g in per_env)
+            # (a fixture batch: ONE agent list describes the slots of every env; otherwise _sensor_args was given one list
+            # per env -- env 0's for the entries that are None -- and `where` names (env, slot) pairs)
+            shared = self._fixture is not None or per_env is None
             for e_, a_ in where:
                 mask[slice(None) if shared else e_, a_] = True
             variants.append((mask, c_, s_))
@@ -414,10 +441,15 @@ class CollisionAvoidanceEnv(Env):
                 for a_, agent in enumerate(g_):
                     if isinstance(agent.policy, RVOPolicy) and agent.policy.heading_noise:
                         noise[slice(None) if self._fixture is not None else e_, a_] = True
-            self._rvo_seed = getattr(self, "_rvo_seed", 0) + 1
-            sim.set_rvo_stochastic(heading_noise=noise if noise.any() else None, collab_coeff=Config.RVO_COLLAB_COEFF,
-                                   anti_collab_t=Config.RVO_ANTI_COLLAB_T,
-                                   seed=int(np.random.randint(1 << 31)) + self._rvo_seed)
+            if noise.any() or Config.RVO_COLLAB_COEFF < 0:
+                # (the seed comes out of numpy's global stream, like the reference's own draws -- only when a stochastic
+                # branch is on: a deterministic batch must not shift the stream the scenario builders draw from)
+                self._rvo_seed = getattr(self, "_rvo_seed", 0) + 1
+                sim.set_rvo_stochastic(heading_noise=noise if noise.any() else None, collab_coeff=Config.RVO_COLLAB_COEFF,
+                                       anti_collab_t=Config.RVO_ANTI_COLLAB_T,
+                                       seed=int(np.random.randint(1 << 31)) + self._rvo_seed)
+            else:
+                sim.set_rvo_stochastic()
         else:
             sim.set_rvo_stochastic()
         nets = [a.policy for g in groups for a in g if isinstance(a.policy, GA3CCADRLPolicy)]
@@ -455,6 +487,13 @@ class CollisionAvoidanceEnv(Env):
         host_any = (bool(self._host_policies) or bool(self._host_by_env and any(self._host_by_env)) or
                     bool(self._host_dynamics) or bool(self._hostdyn_by_env and any(self._hostdyn_by_env)))
         sim.fresh_outputs = E > 1 and not self.zero_copy and not nets and not host_any
+        # the look-ahead ring (see __init__): every policy answered inside the step kernel, nothing between two steps
+        self._la_on = bool(E > 1 and self.lookahead > 0 and not nets and not host_any and not Config.USE_STATIC_MAP and
+                           not any(a.policy.is_external for g in groups for a in g) and sim.lookahead_ok())
+        sim.enable_lookahead(self.lookahead if self._la_on else 0, fresh=not self.zero_copy)
+        self._la_dt_ok = sim.p.dt == self.dt_nominal
+        if self._la_on:
+            self._learning_info = {a.id: a.policy.is_still_learning for a in self.agents}
         if Config.USE_STATIC_MAP:  # collision_avoidance_env.py:273-274, :378-392: Map(16 m, 16 m, 0.1 m)
             sm = self.static_map_filename
             if isinstance(sm, list) and sm and isinstance(sm[0], str):
@@ -568,7 +607,7 @@ class CollisionAvoidanceEnv(Env):
 
     def _write_agent(self, e, a, **fields):
         for name, v in fields.items():
-            self._sim.state[name][e, a] = float(v)
+            self._sim.state[name][e, a] = float(v)   # (`state` rewinds a look-ahead ring to the step last handed out)
         self._sim.invalidate_plan()   # (a host write to the state: the pipelined policy query is forgotten)
         self._snap = None
 

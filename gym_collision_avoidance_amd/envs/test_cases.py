@@ -190,7 +190,8 @@ def make_testcase_huge(num_test_cases=1, num_agents=100, side_length=25, speed_b
     """[num_test_cases, num_agents, 6] crowd scenarios (test_cases.py:914-976): per agent a speed and a radius, then a start
     at least 2 m (surface to surface) from every earlier START and a goal at least 2 m from every earlier GOAL and 5 m from
     its own start, all rejection-sampled from the square [-side_length, side_length]^2.  Same np.random draws, in the
-    same order, as the reference.  (The step kernels hold at most 64 agents per env: INTEGRATION.md.)"""
+    same order, as the reference.  (Up to 64 agents an env is one workgroup tile of the step kernels; 65 .. 256 agents run the
+    one-thread-per-agent kernel of csrc/cagpu_big.inc over CaOut.workspace -- DESIGN.md section 3c.)"""
     cases = np.empty((num_test_cases, num_agents, 6))
     for c in cases:
         for i in range(num_agents):
@@ -212,6 +213,17 @@ def make_testcase_huge(num_test_cases=1, num_agents=100, side_length=25, speed_b
                 trip = np.linalg.norm(np.array([px - gx, py - gy]))
             c[i] = [px, py, gx, gy, speed, radius]
     return cases
+
+
+def get_testcase_huge(seed=None):
+    """The reference's 100-agent scene (test_cases.py:979-992).  It unpickles `test_cases/100agents.p`, a file the
+    reference repository does not ship (its own call raises FileNotFoundError), written by `make_testcase_huge` with
+    its defaults -- so the scene is drawn here by that function (100 agents in a 50 m square; `seed`: np.random.seed
+    first) and handed to GA3C-CADRL agents with unicycle dynamics like the reference's."""
+    if seed is not None:
+        np.random.seed(seed)
+    return cadrl_test_case_to_agents(make_testcase_huge(1, 100, 25)[0], policies="GA3C_CADRL", agents_dynamics="unicycle",
+                                     agents_sensors=["other_agents_states"])
 
 
 def yaml_to_agents(agents_yaml):

@@ -19,11 +19,12 @@ def shard_env_ids(rank, world_size, envs_per_rank):
     return rank * envs_per_rank, world_size * envs_per_rank
 
 
-def reduce_episode_stats(stats, world_size=None):
-    """all-reduce(sum) of the per-shard float64[8] counters (core.STAT_NAMES).  No-op for a single process."""
+def reduce_episode_stats(stats, world_size=None, force=False):
+    """all-reduce(sum) of the per-shard float64[8] counters (core.STAT_NAMES).  No-op for a single process -- unless
+    `force` and a process group exists (a one-rank group: the collective still runs, on RCCL for backend nccl)."""
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    if world_size > 1:
+    if world_size > 1 or (force and dist.is_available() and dist.is_initialized()):
         stats = stats.clone()
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     return stats

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 9
+#define CAGPU_VERSION 10
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -336,9 +336,23 @@ int cagpu_generate_cases_ragged(int64_t num_cases, int32_t max_agents, int32_t n
 /* n_steps consecutive cagpu_step calls fused into ONE launch (every step still writes its
  * outputs; the buffers hold the last step's).  Envs never interact, so no grid-wide sync is
  * needed.  This is the batched form of env_utils.py:45-52 `while not terminated: env.step(None)`.
- * ext_actions (if any) are held constant over the n_steps. */
+ * ext_actions (if any) are held constant over the n_steps.  The per-step inputs CaState.rvo_collab / rvo_heading_noise /
+ * ext_state belong to the ONE step that consumes them: with n_steps > 1 any of them set is CA_EINVAL. */
 int cagpu_rollout(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions,
                   const CaAutoReset *ar, int32_t n_steps, void *stream);
+
+/* cagpu_rollout whose every step KEEPS its outputs: the look-ahead ring behind `env.step(None)`.  With every policy internal
+ * the reference's `env.step(None)` needs no input from the host (experiments/src/env_utils.py:45-52: `run_episode` passes
+ * None until the episode is over), so the next n_steps steps can be computed in one launch and handed out one by one -- but
+ * a gym caller wants the outputs of EVERY step, not only the last one's.  Here the output pointers of `o` name slot 0 of a
+ * ring of n_steps slots and step t of the call (t = 0 .. n_steps - 1) writes slot t:
+ *   o->obs [n_steps, E, N, 6+7K], o->rewards [n_steps, E, N], o->done [n_steps, E, N], o->game_over [n_steps, E],
+ *   o->actions / o->orca_vel (if given) [n_steps, E, N, 2].
+ * State, statistics and auto-resets are those of cagpu_rollout(n_steps) -- i.e. of n_steps cagpu_step calls, bit for bit
+ * (tests/test_gpu_ring.py).  Like cagpu_rollout it takes no per-step inputs (CaState.rvo_collab / rvo_heading_noise /
+ * ext_state must be NULL: CA_EINVAL; ext_actions, if any, are held constant). */
+int cagpu_rollout_ring(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions,
+                       const CaAutoReset *ar, int32_t n_steps, void *stream);
 
 /* The policy query of the NEXT step ahead of time (collision_avoidance_env.py:305-323 for the built-in RVO policy):
  * fills s->next_action from the CURRENT state and sets CA_PLAN_VALID, without stepping.  cagpu_step / cagpu_rollout keep
@@ -382,6 +396,13 @@ int cagpu_device_faults(uint32_t *faults, int32_t clear);
  * tests/test_gpu_bench_geometry.py runs the CPU oracle on ops 0 / 1 to show that they are the ONLY difference (free-running
  * episodes then agree bit for bit); tests/test_gpu_parity.py pins the operand range in which ops 2 - 5 agree. */
 int cagpu_debug_libm(int32_t op, int32_t n, const double *a, const double *b, double *out0, double *out1);
+
+/* Measurement hook (profiles/ only, no reference analogue): dst[i] = src[i] for n float64 elements with the access shape of
+ * the step kernels' state loads -- ONE 8-byte element per lane and instruction (global_load_dwordx2 / global_store_dwordx2,
+ * 64 consecutive elements per wavefront), device pointers, asynchronous on `stream`.  Its traffic is known exactly (8 n
+ * bytes read, 8 n written), which is what the rocprofv3 FETCH_SIZE / WRITE_SIZE counters of the step kernels are calibrated
+ * against (profiles/r05_traffic.json: the counters under-report this pattern on gfx950). */
+int cagpu_debug_copy8(int64_t n, const double *src, double *dst, void *stream);
 
 #ifdef __cplusplus
 }

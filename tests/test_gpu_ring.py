@@ -1,0 +1,264 @@
+"""The look-ahead ring behind `env.step(None)` (cagpu_rollout_ring, core.BatchedSim.step_lookahead, the `lookahead` argument
+of CollisionAvoidanceEnv): with every policy internal the next K steps are computed in ONE launch of the fused n-step
+kernel and handed out slot by slot.  The bar: slot t of the ring IS what the one-launch-per-step path returns for that
+step -- outputs and state bit for bit, auto-resets included -- at the metric's batch and at BASELINE configs[1]; the
+one-launch-per-step path is held to the CPU oracle block by block in the same loop, so the ring is too.  And whatever needs
+the simulator at the step last handed out (state reads, resets, actions, another dt, parameter changes, the episode
+statistics) rewinds transparently."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from tests import envtools  # noqa: E402
+from tests.test_gpu_bench_geometry import Block, _bench, _blocks  # noqa: E402
+from tests.test_gpu_parity import F64, _mods  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+STATE = F64 + ("last_action", "flags", "step_num", "episode_step", "reset_count", "env_stats", "next_action")
+
+
+def _same_state(a, b, what):
+    for n in STATE:
+        x, y = a.state[n], b.state[n]
+        if n == "next_action":   # (only the rows flagged CA_PLAN_VALID mean anything; both paths flag the same rows)
+            nat = _mods()[0]
+            ok = (a.state["flags"] & nat.PLAN_VALID) != 0
+            x, y = x[ok], y[ok]
+        assert torch.equal(x, y), "%s differs %s" % (n, what)
+
+
+@pytest.mark.parametrize("E,K", [(4096, 32), (1024, 32), (4096, 7)])
+def test_ring_slot_equals_single_launch_bit_for_bit_and_oracle_blocks(E, K):
+    """300 steps with auto-resets: every slot of the ring equals the outputs of the single-launch path bit for bit, the
+    states agree bit for bit whenever they are compared (at ring boundaries and in the middle of a ring: a rewind), and
+    the single-launch path is stepped by the oracle block by block from its own bits all along"""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    a, table, N, _ = _bench().build_workload("rvo10", E, dev)   # one launch per step
+    b, _, _, _ = _bench().build_workload("rvo10", E, dev)       # the ring
+    a.rollout(150)
+    b.rollout(150)
+    b.enable_lookahead(K, fresh=True)
+    blocks = [Block(a, b0, 16, table, orc.POL_RVO) for b0 in _blocks(E, 16, 4, E + K)]
+    held, ended, resets0 = [], 0, int(a.state["reset_count"].sum())
+    for t in range(300):
+        for blk in blocks:
+            blk.download()
+        oa, ra, ga = a.step()
+        assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4, false>")
+        ob, rb, db, gb = b.step_lookahead()
+        if t % K == 0:
+            assert nat.lib().cagpu_last_kernel().decode().startswith("ca_pipe_kernel<10, 4, true>")
+        assert torch.equal(oa, ob) and torch.equal(ra, rb), "obs / rewards of step %d" % t
+        assert torch.equal(a.done.view(torch.bool), db) and torch.equal(ga.view(torch.bool), gb), "done / game_over of step %d" % t
+        if t in (40, 130):      # a slot handed out earlier stays what it was (a fresh ring per refill)
+            held.append((ob, ob.clone()))
+        for blk in blocks:
+            blk.step()
+            blk.compare("E=%d block %d step %d" % (E, blk.b0, t))
+            ended += int(blk.o.game_over.sum())
+        if t in (K - 1, 2 * K - 1, 100, 257):   # ring boundaries (nothing to rewind) and mid-ring (restore + re-run)
+            _same_state(a, b, "after step %d" % t)
+            assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards)
+    _same_state(a, b, "at the end")
+    assert ended > 0 and int(a.state["reset_count"].sum()) > resets0 + E // 4, "auto-resets must fall into the window"
+    for view, copy in held:
+        assert torch.equal(view, copy)
+    assert torch.equal(a.episode_stats(), b.episode_stats())
+    assert b._la["fills"] >= 300 // K
+
+
+def test_ring_c_abi_layout_and_argument_checks():
+    """cagpu_rollout_ring through the C ABI: slot t of every output of ONE call = step t of a cagpu_rollout; the per-step
+    inputs are refused by multi-step calls (they belong to the step that consumes them)"""
+    import ctypes as C
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    E, n = 333, 9
+    for N, kern in ((10, "ca_pipe_kernel<10, 4, true>"), (4, "ca_pipe_kernel<4, 16, true>"), (20, "ca_kernel<256, "),
+                    (7, "ca_kernel<256, ")):
+        table = np.load(os.path.join(REPO, "gym_collision_avoidance_amd", "data", "test_cases.npz"))["n%d" % (N if N != 7 else 8)][:, :N]
+        sims = []
+        for _ in range(2):
+            s = core.BatchedSim(core.make_params(E, N), device=dev, record_actions=True)
+            s.set_plugins(nat.POL_RVO)
+            s.set_fixture_table(table)
+            s.reset_from_table()
+            s.rollout(60)
+            sims.append(s)
+        a, b = sims
+        W = b.W
+        ring = dict(obs=torch.full((n, E, N, W), -7.0, device=dev), rewards=torch.full((n, E, N), -7.0, device=dev),
+                    done=torch.full((n, E, N), 9, dtype=torch.uint8, device=dev),
+                    game_over=torch.full((n, E), 9, dtype=torch.uint8, device=dev),
+                    actions=torch.full((n, E, N, 2), -7.0, device=dev), orca_vel=torch.full((n, E, N, 2), -7.0, device=dev))
+        co = nat.CaOut.from_buffer_copy(b._co)
+        for k_, v in ring.items():
+            setattr(co, k_, v.data_ptr())
+        nat.check(b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, C.byref(b._ar), n, b._stream()))
+        assert nat.lib().cagpu_last_kernel().decode().startswith(kern), nat.lib().cagpu_last_kernel().decode()
+        for t in range(n):
+            a.step()
+            assert torch.equal(ring["obs"][t], a.obs) and torch.equal(ring["rewards"][t], a.rewards), (N, t)
+            assert torch.equal(ring["done"][t], a.done) and torch.equal(ring["game_over"][t], a.game_over), (N, t)
+            assert torch.equal(ring["actions"][t], a.actions) and torch.equal(ring["orca_vel"][t], a.orca_vel), (N, t)
+        for nme in F64 + ("flags", "step_num", "reset_count", "env_stats"):
+            x, y = a.state[nme], b.state[nme]
+            if nme == "flags":
+                x, y = x & ~nat.PLAN_VALID, y & ~nat.PLAN_VALID
+            assert torch.equal(x, y), (N, nme)
+    # per-step inputs + a multi-step call
+    noise = torch.zeros((E, 7), dtype=torch.float64, device=dev)
+    b._cs.rvo_heading_noise = noise.data_ptr()
+    try:
+        assert b.lib.cagpu_rollout(C.byref(b.p), C.byref(b._cs), C.byref(b._co), None, None, 3, b._stream()) == nat.CA_EINVAL
+        assert b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, None, 1, b._stream()) == nat.CA_EINVAL
+        assert b.lib.cagpu_step(C.byref(b.p), C.byref(b._cs), C.byref(b._co), None, None, b._stream()) == 0
+    finally:
+        b._cs.rvo_heading_noise = None
+
+
+def test_ring_of_a_large_batch_and_of_big_envs():
+    """the n-step launch of a grid of many rounds (32 768 x 10) and the launcher's n-single-launch forms (a generic-N batch
+    that is not resident at once; envs of more than 64 agents) fill the ring like n steps do"""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    a, table, N, _ = _bench().build_workload("rvo10", 32768, dev)
+    b, _, _, _ = _bench().build_workload("rvo10", 32768, dev)
+    a.rollout(100)
+    b.rollout(100)
+    b.enable_lookahead(5)
+    for t in range(10):
+        oa, ra, ga = a.step()
+        ob, rb, db, gb = b.step_lookahead()
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ga.view(torch.bool), gb), t
+    _same_state(a, b, "32768 envs")
+    del a, b
+    for E, N in ((8000, 12), (6, 100)):
+        rng = np.random.default_rng(N)
+        tab = np.zeros((40, N, 6))
+        side = 6.0 if N == 12 else 25.0
+        tab[..., 0:2] = rng.uniform(-side, side, (40, N, 2))
+        tab[..., 2:4] = rng.uniform(-side, side, (40, N, 2))
+        tab[..., 4] = rng.uniform(0.5, 2.0, (40, N))
+        tab[..., 5] = rng.uniform(0.2, 0.5, (40, N))
+        sims = []
+        for _ in range(2):
+            s = core.BatchedSim(core.make_params(E, N), device=dev)
+            s.set_plugins(nat.POL_RVO)
+            s.set_fixture_table(tab)
+            s.reset_from_table()
+            sims.append(s)
+        a, b = sims
+        b.enable_lookahead(4)
+        for t in range(9):
+            oa, ra, ga = a.step()
+            ob, rb, db, gb = b.step_lookahead()
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(a.done.view(torch.bool), db), (N, t)
+        for nme in F64 + ("step_num", "reset_count"):
+            assert torch.equal(a.state[nme], b.state[nme]), (N, nme)
+
+
+def test_sync_rewinds_for_everything_that_needs_the_current_step():
+    """mid-ring: a masked reset, a parameter change, a plain step() with external inputs, an explicit rollout and the episode
+    statistics all see the state of the step last handed out -- and the ring carries on from there"""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    E = 777
+    a, table, N, _ = _bench().build_workload("rvo10", E, dev)
+    b, _, _, _ = _bench().build_workload("rvo10", E, dev)
+    b.enable_lookahead(16, fresh=False)   # ONE persistent ring (the zero_copy form)
+    both = lambda f: (f(a), f(b))
+
+    def run(n):
+        for _ in range(n):
+            oa, ra, ga = a.step()
+            ob, rb, db, gb = b.step_lookahead()
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(a.done.view(torch.bool), db)
+    run(21)
+    mask = (torch.arange(E, device=dev) % 3 == 0).to(torch.uint8)
+    both(lambda s: s.reset(torch.as_tensor(table[(np.arange(E) + 5) % 500], device=dev), mask=mask))
+    assert torch.equal(a.obs, b.obs)
+    run(9)
+    both(lambda s: s.update_params(rvo_time_horizon=3.0))
+    run(20)
+    ext = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
+    both(lambda s: s.step(ext))
+    assert torch.equal(a.obs, b.obs)
+    run(5)
+    both(lambda s: s.rollout(3))
+    run(18)
+    assert torch.equal(a.episode_stats(), b.episode_stats())
+    run(3)
+    both(lambda s: s.reset_from_table())     # a full reset drops the ring without a rewind
+    run(40)
+    _same_state(a, b, "at the end")
+    b.enable_lookahead(0)
+    assert b._la is None and torch.equal(a.obs, b.obs)
+    # a batch that needs work between two steps cannot run ahead
+    c, _, _, _ = _bench().build_workload("rvo10", 64, dev)
+    c.set_rvo_stochastic(heading_noise=np.ones((64, N), bool), seed=1)
+    c.enable_lookahead(8)
+    assert not c.lookahead_ok()
+    with pytest.raises(nat.CagpuError):
+        c.step_lookahead()
+
+
+def test_env_api_serves_step_none_from_the_ring():
+    """CollisionAvoidanceEnv(num_envs=E).step(None) with the default look-ahead == the same env with lookahead=0, step by
+    step, through agent-state reads, a custom dt, external-action steps and a reset; what step() returns stays the
+    caller's (fresh ring per refill)"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    E = 512
+    envs = []
+    for la in (0, None):
+        env = Env(num_envs=E, lookahead=la)
+        env.set_fixture_suite(10, "RVO")
+        env.reset()
+        envs.append(env)
+    ref, la = envs
+    assert la._la_on and not ref._la_on and la.lookahead == Env.LOOKAHEAD_DEFAULT and ref._sim._la is None
+    kept = []
+
+    def same(n, **kw):
+        for _ in range(n):
+            o0, r0, g0, _, i0 = ref.step(None, **kw)
+            o1, r1, g1, _, i1 = la.step(None, **kw)
+            assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(g0, g1)
+            assert torch.equal(i0["which_agents_done"], i1["which_agents_done"])
+            assert i0["which_agents_learning"] == i1["which_agents_learning"]
+            assert g1.dtype == torch.bool and i1["which_agents_done"].dtype == torch.bool
+            kept.append((o1, o1.clone()))
+    same(45)
+    assert la._sim._la["fills"] == 2 and la._sim._la["t"] == 45 - 32
+    # reading an agent (a view of the device state) sees the step last handed out, not the end of the ring
+    assert np.array_equal(ref.agents[3].pos_global_frame, la.agents[3].pos_global_frame)
+    assert ref.agents[3].t == la.agents[3].t and ref.episode_step_number == la.episode_step_number
+    same(10)
+    same(3, dt=0.05)            # another dt: stepped one launch at a time, then back to the ring
+    same(40)
+    assert la._sim._la["slots"] is not None
+    assert ref.episode_stats() == la.episode_stats()
+    same(7)
+    for env in envs:
+        env.reset()
+    same(70)
+    for view, copy in kept:
+        assert torch.equal(view, copy)
+    for n in F64 + ("flags", "step_num"):
+        assert torch.equal(ref._sim.state[n], la._sim.state[n]), n
+    # a scene with an external policy keeps the one-launch-per-step path
+    env = Env(num_envs=4)
+    env.set_agents([tc.cadrl_test_case_to_agents(tc.preset_testCases(2)[0], policies=["external", "RVO"]) for _ in range(4)])
+    env.reset()
+    assert not env._la_on
+    envtools.default()
