@@ -2271,6 +2271,13 @@ int cagpu_observe(const CaParams* p, const CaState* s, const CaOut* o, void* str
   return launch_any(k, stream);
 }
 
+#ifdef CAGPU_STEPTIME
+int cagpu_debug_steptime(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pipe::g_steptime), sizeof(unsigned long long) * 1024 * 66);
+  return 0;
+}
+#endif
 #ifdef CAGPU_PIPETIME
 int cagpu_debug_pipetime(unsigned long long* out) {
   (void)hipDeviceSynchronize();

@@ -58,7 +58,7 @@ class _HostAgent(object):
 class CollisionAvoidanceEnv(Env):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
 
-    LOOKAHEAD_DEFAULT = 32
+    LOOKAHEAD_DEFAULT = 64
 
     def __init__(self, num_envs=1, device="cuda:0", zero_copy=False, lookahead=None):
         """zero_copy (batched mode only): False -- step() / rollout() / reset() return FRESH tensors, like the

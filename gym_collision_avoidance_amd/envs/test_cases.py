@@ -40,15 +40,16 @@ dynamics_dict = {"unicycle": UnicycleDynamics, "unicycle_max_turn_rate": Unicycl
 _tables = {}
 
 
-def fixture_table(num_agents):
-    """float64 [500, N, 6] = px, py, gx, gy, pref_speed, radius: the reference's {N}_agents_500_cases.p."""
-    if num_agents not in _tables:
+def fixture_table(num_agents, carrl=False, seed=None):
+    """float64 [500, N, 6] = px, py, gx, gy, pref_speed, radius: the reference's {N}_agents_500_cases.p; carrl / seed: its
+    `_carrl` / `_carrl_seed00x` variants (test_cases.py:618-622; shipped for two agents, seeds 0 .. 4)."""
+    key = "n%d" % num_agents + ("_carrl" if carrl else "") + ("_seed%03d" % seed if seed is not None else "")
+    if key not in _tables:
         with np.load(_DATA) as z:
-            key = "n%d" % num_agents
-            if key not in z:
-                raise FileNotFoundError("no 500-case fixture for %d agents (have: %s)" % (num_agents, sorted(z.keys())))
-            _tables[num_agents] = z[key]
-    return _tables[num_agents]
+            if key not in z:  # (the reference fails the same way: open() of a pickle it does not ship)
+                raise FileNotFoundError("no 500-case fixture %r (have: %s)" % (key, sorted(z.keys())))
+            _tables[key] = z[key]
+    return _tables[key]
 
 
 _presets = None
@@ -61,9 +62,10 @@ def preset_testCases(num_agents, full_test_suite=False, vpref_constraint=False, 
     data/presets.npz -- recorded from the imported reference by oracle/gen_presets.py, like the fixture tables."""
     global _presets
     if full_test_suite:
-        if vpref_constraint or carrl or seed is not None:
-            raise NotImplementedError("only the plain {N}_agents_500_cases fixtures are shipped")
-        return list(fixture_table(num_agents))
+        if vpref_constraint:   # test_cases.py:603-607: a `vpref1.0_r<lo>-<hi>/` directory the reference does not ship either
+            raise FileNotFoundError("the vpref_constraint fixtures (test_cases/vpref1.0_r%s-%s/) are not part of the "
+                                    "reference repository" % tuple(radius_bounds or ("?", "?")))
+        return list(fixture_table(num_agents, carrl=carrl, seed=seed))
     if _presets is None:
         with np.load(os.path.join(os.path.dirname(_DATA), "presets.npz")) as z:
             _presets = {k: z[k] for k in z.files}

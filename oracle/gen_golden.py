@@ -250,6 +250,12 @@ def fixtures():
             cases = pickle.load(f, encoding="latin1")
         out["n%d" % n] = np.array([np.asarray(c, dtype=np.float64) for c in cases])
         assert out["n%d" % n].shape == (500, n, 6)
+    # the CARRL fixture family (preset_testCases(2, full_test_suite=True, carrl=True[, seed=0..4]), test_cases.py:618-622)
+    for suffix in ("_carrl",) + tuple("_carrl_seed%03d" % sd for sd in range(5)):
+        with open(os.path.join(d, "2_agents_500_cases%s.p" % suffix), "rb") as f:
+            cases = pickle.load(f, encoding="latin1")
+        out["n2" + suffix] = np.array([np.asarray(c, dtype=np.float64) for c in cases])
+        assert out["n2" + suffix].shape == (500, 2, 6)
     os.makedirs(DATA, exist_ok=True)
     np.savez_compressed(os.path.join(DATA, "test_cases.npz"), **out)
     print("fixtures ok", {k: v.shape for k, v in out.items()})

@@ -790,3 +790,83 @@ def test_training_mode_reset_headings_differ_between_resets_and_shards():
         heads.append(h1)
     assert np.array_equal(heads[0], heads[1]) and not np.array_equal(heads[0], heads[2])   # reproducible; shards differ
     envtools.default()
+
+
+def test_reference_example_runs_unmodified_under_the_import_alias():
+    """The caller-side lines of the reference's minimum working example (experiments/src/example.py:3-9 and :24-66: imports,
+    gym.make, set_plot_save_dir, get_testcase_two_agents + initialize_network, set_agents, reset, 100 x step({0: action}))
+    run AS WRITTEN against this package once `install_as(provide_gym=True)` has been called -- the one line a user adds.
+    (Lines :17-22 of the file open a TensorFlow session, which this package has no use for.)  In a child process: the alias
+    is a process-wide import hook."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import gym_collision_avoidance_amd; gym_collision_avoidance_amd.install_as(provide_gym=True)   # <- the one added line
+# ---- experiments/src/example.py:1-9 ---------------------------------------------------------------------------------
+import os
+
+import gym
+import numpy as np
+
+gym.logger.set_level(40)
+os.environ["GYM_CONFIG_CLASS"] = "Example"
+from gym_collision_avoidance.envs import Config
+from gym_collision_avoidance.envs import test_cases as tc
+
+
+def main():
+    # ---- experiments/src/example.py:24-66 ---------------------------------------------------------------------------
+    # Instantiate the environment
+    env = gym.make("CollisionAvoidance-v0")
+
+    # In case you want to save plots, choose the directory
+    env.set_plot_save_dir(
+        os.path.dirname(os.path.realpath(__file__))
+        + "/../../experiments/results/example/"
+    )
+
+    # Set agent configuration (start/goal pos, radius, size, policy)
+    agents = tc.get_testcase_two_agents()
+    [
+        agent.policy.initialize_network()
+        for agent in agents
+        if hasattr(agent.policy, "initialize_network")
+    ]
+    env.set_agents(agents)
+
+    obs = env.reset()  # Get agents' initial observations
+
+    # Repeatedly send actions to the environment based on agents' observations
+    num_steps = 100
+    for i in range(num_steps):
+        actions = {}
+        actions[0] = np.array([1.0, 0.5])
+        obs, rewards, terminated, truncated, which_agents_done = env.step(
+            actions
+        )
+
+        if terminated:
+            print("All agents finished!")
+            break
+    env.reset()
+
+    return True, i, env
+
+
+ok, steps, env = main()
+assert ok and type(Config).__name__ == "Example" and type(env).__name__ == "CollisionAvoidanceEnv"
+assert type(env).__module__ == "gym_collision_avoidance_amd.envs.collision_avoidance_env"
+assert 5 < steps <= 99 and len(env.agents) == 2
+print("example ok after", steps + 1, "steps")
+'''
+    env = {k: v for k, v in os.environ.items() if k not in ("GYM_CONFIG_CLASS", "GYM_CONFIG_PATH")}
+    script = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cagpu_ref_example_%d.py" % os.getpid())
+    with open(script, "w") as f:
+        f.write(code % repo)
+    try:
+        r = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    finally:
+        os.remove(script)
+    assert r.returncode == 0 and b"example ok" in r.stdout, r.stdout.decode()[-3000:]

@@ -422,3 +422,49 @@ def test_plugin_descriptors_of_user_classes_and_sensor_argument_groups():
     proxy.pos_global_frame += 1.0
     assert np.allclose(agents[1].pos_global_frame, [1.0, 0.0]) and np.allclose(proxy.pos_global_frame, [2.0, 1.0])
     assert proxy.pref_speed == agents[1].pref_speed and proxy.id == 1
+
+
+def test_install_as_aliases_the_package_under_the_reference_name(tmp_path):
+    """gym_collision_avoidance_amd.install_as(): the reference's import lines resolve to THIS package's module objects
+    (one Config singleton), `experiments.src.*` maps to `experiments.*`, unknown names fail like any missing module, the
+    gym stand-in is lazy (importing it does not instantiate Config) and an existing package of that name is not shadowed.
+    Runs in a child process: the alias is a process-wide import hook."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import gym_collision_avoidance_amd as pkg
+assert pkg.install_as(provide_gym=True) == "gym_collision_avoidance"
+pkg.install_as()                                     # idempotent
+import gym
+gym.logger.set_level(40)
+assert not any(m.startswith("gym_collision_avoidance_amd.envs") for m in sys.modules)
+os.environ["GYM_CONFIG_CLASS"] = "Example"           # (the caller selects the Config class before its first import)
+from gym_collision_avoidance.envs import Config
+from gym_collision_avoidance.envs import test_cases as tc
+import gym_collision_avoidance_amd.envs as E, gym_collision_avoidance_amd.envs.test_cases as TC
+assert Config is E.Config and tc is TC and type(Config).__name__ == "Example"
+from gym_collision_avoidance.experiments.src.env_utils import run_episode
+import gym_collision_avoidance_amd.experiments.env_utils as EU
+assert run_episode is EU.run_episode
+from gym_collision_avoidance.envs.policies.RVOPolicy import RVOPolicy
+from gym_collision_avoidance.envs.agent import Agent
+from gym_collision_avoidance_amd.envs.agent import Agent as A2
+assert Agent is A2 and gym.spaces.Box is E.spaces.Box
+try:
+    import gym_collision_avoidance.no_such_module
+    raise SystemExit("missing module imported")
+except ModuleNotFoundError:
+    pass
+os.makedirs(os.path.join(%r, "other_pkg"))
+open(os.path.join(%r, "other_pkg", "__init__.py"), "w").close()
+sys.path.insert(0, %r)
+try:
+    pkg.install_as("other_pkg")
+    raise SystemExit("shadowed an importable package")
+except ImportError:
+    pass
+print("alias ok")
+''' % (REPO, str(tmp_path), str(tmp_path), str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("GYM_CONFIG_CLASS", "GYM_CONFIG_PATH")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and b"alias ok" in r.stdout, r.stdout.decode()[-2000:]
