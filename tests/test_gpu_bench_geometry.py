@@ -201,6 +201,70 @@ def test_config3_4096x20_ga3c_vs_oracle():
     assert envs_cmp >= 0.9 * 25 * sum(b.n for b in blocks)
 
 
+def test_config3_episode_outcomes_free_running_vs_oracle():
+    """What the argmax choices that differ between the kernel's network and the numpy one (< 0.5 %, all within 1e-3 of a tie)
+    do to EPISODES: 2048 twenty-agent GA3C-CADRL scenes (drawn by cagpu_generate_cases, sides 6 .. 8 m like the n20 fixture)
+    run to their end free-running on the GPU and, from the same cases, free-running in the oracle (C++ step + numpy network);
+    collision / all-at-goal / stuck rates must agree within 3 sigma of two binomial samples of this size, and so must the
+    mean episode length."""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    E, N, K, T = 2048, 20, 19, 700
+    sim = core.BatchedSim(core.make_params(E, N, max_obs=K, sort_mode=nat.SORT_CLOSEST_LAST), device=dev)
+    sim.set_plugins(nat.POL_GA3C_CADRL, nat.DYN_UNICYCLE)
+    sim.load_ga3c()
+    cases = sim.generate_cases(E, seed=2024, side_length=(6.0, 8.0))
+    sim.reset(cases)
+    # the oracle side (C++ step + numpy network, ~2 s per 100 steps of 256 envs) on 16 processes of 128 envs each, started
+    # first so that they run beside the GPU's part
+    import multiprocessing as mp
+    from tests import oracle_workers
+    host_cases = cases.cpu().numpy()
+    keep = {k_: os.environ.get(k_) for k_ in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update({k_: "4" for k_ in keep})      # (inherited by the workers: 16 processes x 4 BLAS threads)
+    try:
+        pool = mp.get_context("spawn").Pool(16)
+    finally:
+        for k_, v_ in keep.items():
+            os.environ.pop(k_, None) if v_ is None else os.environ.__setitem__(k_, v_)
+    pending = pool.map_async(oracle_workers.ga3c_episodes, [(host_cases[i:i + 128], T) for i in range(0, E, 128)])
+    o1 = orc.Oracle(orc.default_params(128, N, max_obs=K, sort_mode=orc.SORT_CLOSEST_LAST))
+    o1.set_policies(orc.POL_GA3C_CADRL)
+    o1.reset(host_cases[:128])
+    np.testing.assert_allclose(sim.obs[:128].cpu().numpy(), o1.obs, rtol=0, atol=1e-5)
+    g_len = np.zeros(E)
+    g_over = torch.zeros(E, dtype=torch.bool, device=dev)
+    for t in range(T):
+        sim.step()
+        g_len += (~g_over).cpu().numpy()
+        g_over |= sim.game_over.view(torch.bool)
+        if bool(g_over.all()):
+            break
+    parts = pending.get(timeout=900)
+    pool.close()
+    o_flags = np.concatenate([p_[0] for p_ in parts])
+    o_over = np.concatenate([p_[1] for p_ in parts])
+    o_len = np.concatenate([p_[2] for p_ in parts])
+
+    def outcomes(flags, over):
+        f = flags.reshape(E, N)
+        coll = ((f & (orc.IN_COLLISION | orc.WAS_IN_COLLISION)) != 0).any(axis=1)
+        goal = ((f & orc.AT_GOAL) != 0).all(axis=1)
+        return np.array([(coll & over).mean(), (goal & ~coll & over).mean(), (~coll & ~goal & over).mean(), (~over).mean()])
+    pg = outcomes(sim.state["flags"].cpu().numpy().astype(np.uint32), g_over.cpu().numpy())
+    po = outcomes(o_flags, o_over)
+    names = ("collision", "all at goal", "stuck / out of time", "unfinished after %d steps" % T)
+    for nme, a, b in zip(names, pg, po):
+        bound = 3.0 * np.sqrt((a * (1 - a) + b * (1 - b)) / E) + 1.0 / E
+        assert abs(a - b) <= bound, "%s: GPU %.4f oracle %.4f (3 sigma = %.4f)" % (nme, a, b, bound)
+    assert pg[0] + pg[1] > 0.5 and po[3] < 0.2, (pg, po)      # (the window holds most episodes to their end)
+    se = np.sqrt((g_len.var() + o_len.var()) / E)
+    assert abs(g_len.mean() - o_len.mean()) <= 3.0 * se + 0.5, (g_len.mean(), o_len.mean(), se)
+    same = (g_len == o_len).mean()
+    print("config-3 episodes: GPU %s oracle %s; mean length %.1f / %.1f; %.1f %% of the episodes end in the same step" % (
+        np.round(pg, 4), np.round(po, 4), g_len.mean(), o_len.mean(), 100 * same))
+
+
 # ---------------------------------------------------------------- config 5
 def test_config5_4096x50_map_laserscan_vs_oracle():
     """BASELINE configs[4]: 4096 x 50 RVO agents + static map (wall collisions) + 512-beam LaserScanSensor"""
