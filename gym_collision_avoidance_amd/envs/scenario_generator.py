@@ -180,12 +180,41 @@ def generate_rand_case(num_agents, side_length, speed_bnds, radius_bnds, is_end_
     return case
 
 
+def generate_static_case(num_agents, side_length, speed_bnds, radius_bnds):
+    """agent 0 crosses the square from left to right, every other agent stands still (start = goal): agent 1 at the origin,
+    the rest rejection-sampled in the inner half of a square that grows 1 % per rejected attempt
+    (gen_rand_testcases.py:263-317).  Same np.random draws in the same order as the reference."""
+    case = np.zeros((num_agents, 6))
+    for i in range(num_agents):
+        _draw_body(case, i, speed_bnds, radius_bnds)
+        if i == 0:
+            start = side_length * 2.0 * np.random.rand(2,) - side_length
+            end = side_length * 2.0 * np.random.rand(2,) - side_length
+            start[0] = min(-1.5, -np.random.rand() * side_length)
+            start[1] = np.random.rand() * 2.0 - 1.0
+            end[0] = max(1.5, np.random.rand() * side_length)
+            end[1] = np.random.rand() * 2.0 - 1.0
+        elif i == 1:
+            start = np.zeros((2,))
+            end = start
+        else:
+            while True:
+                start = (side_length * 2 * np.random.rand(2,) - side_length) / 2.0
+                end = start
+                if not _overlaps_earlier(case, i, start, end):
+                    break
+                side_length *= 1.01
+        case[i, 0:2] = start
+        case[i, 2:4] = end
+    return case
+
+
 def generate_rand_test_case_multi(num_agents, side_length, speed_bnds, radius_bnds, is_end_near_bnd=False,
                                   is_static=False):
     """15 % swap, 15 % circle, 70 % random (gen_rand_testcases.py:111-142)"""
+    dice = np.random.rand()   # (drawn before the is_static test, like the reference: the stream position is part of the result)
     if is_static:
-        raise NotImplementedError("generate_static_case is not restated (no caller in the env path)")
-    dice = np.random.rand()
+        return generate_static_case(num_agents, side_length, speed_bnds, radius_bnds)
     if dice < 0.15:
         return generate_swap_case(num_agents, side_length, speed_bnds, radius_bnds)
     if dice > 0.15 and dice < 0.3:

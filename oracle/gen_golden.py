@@ -303,6 +303,10 @@ def rand_cases():
         n, side = 2 + seed % 9, 4.0 + (seed % 5)
         np.random.seed(seed)
         out["multi_%d" % seed] = np.asarray(rtc.tc.generate_rand_test_case_multi(n, side, [0.5, 2.0], [0.2, 0.8]))
+    for seed in range(12):          # the static-obstacle family (is_static=True: generate_static_case, gen_rand_testcases.py:263-317)
+        n, side = 2 + seed % 7, 3.0 + (seed % 4)
+        np.random.seed(500 + seed)
+        out["static_%d" % seed] = np.asarray(rtc.tc.generate_rand_test_case_multi(n, side, [0.5, 2.0], [0.2, 0.8], is_static=True))
     args = dict(Config.TEST_CASE_ARGS)
     for seed in range(20):          # the env's default reset path (collision_avoidance_env.py:345-362)
         np.random.seed(1000 + seed)

@@ -243,6 +243,12 @@ def test_random_scenarios_match_the_reference_bit_for_bit():
         got = sg.generate_rand_test_case_multi(n, side, [0.5, 2.0], [0.2, 0.8])
         assert np.array_equal(got, z["multi_%d" % seed]), seed
     assert kinds == {"swap", "circle", "rand"}
+    for seed in range(12):     # the static-obstacle family (is_static=True -> generate_static_case)
+        n, side = 2 + seed % 7, 3.0 + (seed % 4)
+        np.random.seed(500 + seed)
+        got = sg.generate_rand_test_case_multi(n, side, [0.5, 2.0], [0.2, 0.8], is_static=True)
+        assert np.array_equal(got, z["static_%d" % seed]), seed
+        assert n < 2 or (np.array_equal(got[1:, 0:2], got[1:, 2:4]) and got[0, 0] <= -1.5 <= 1.5 <= got[0, 2])
     assert int(z["max_agents"]) == Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
     ref_args = json.loads(str(z["test_case_args"]))
     assert ref_args["policies"] == Config.TEST_CASE_ARGS["policies"] and \
@@ -468,3 +474,32 @@ print("alias ok")
     env = {k: v for k, v in os.environ.items() if k not in ("GYM_CONFIG_CLASS", "GYM_CONFIG_PATH")}
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0 and b"alias ok" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def test_carrl_fixture_family_and_huge_testcase():
+    """preset_testCases(2, full_test_suite=True, carrl=True[, seed=k]) serves the reference's `_carrl` / `_carrl_seed00k` pickles
+    (test_cases.py:618-622; shipped as data like the plain suites); a fixture the reference does not ship fails the same
+    way its open() would; get_testcase_huge builds the 100-agent scene make_testcase_huge draws with its defaults"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    plain = tc.preset_testCases(2, full_test_suite=True)
+    carrl = tc.preset_testCases(2, full_test_suite=True, carrl=True)
+    seeds = [tc.preset_testCases(2, full_test_suite=True, carrl=True, seed=k) for k in range(5)]
+    assert len(plain) == len(carrl) == 500 and all(len(s_) == 500 and s_[0].shape == (2, 6) for s_ in seeds)
+    assert not np.array_equal(np.array(plain), np.array(carrl)) and not np.array_equal(np.array(seeds[0]), np.array(seeds[1]))
+    if os.path.isdir("/root/reference"):   # (build container: the data equal the pickles byte for byte)
+        import pickle
+        d = "/root/reference/gym_collision_avoidance/envs/test_cases/"
+        for name, got in (("2_agents_500_cases_carrl.p", carrl), ("2_agents_500_cases_carrl_seed003.p", seeds[3])):
+            with open(d + name, "rb") as f:
+                want = pickle.load(f, encoding="latin1")
+            assert all(np.array_equal(np.asarray(w_, np.float64), g_) for w_, g_ in zip(want, got))
+    with pytest.raises(FileNotFoundError):
+        tc.preset_testCases(3, full_test_suite=True, carrl=True)
+    with pytest.raises(FileNotFoundError):
+        tc.preset_testCases(2, full_test_suite=True, vpref_constraint=True, radius_bounds=[0.2, 0.8])
+    agents = tc.get_testcase_huge(seed=5)
+    np.random.seed(5)
+    want = tc.make_testcase_huge(1, 100, 25)[0]
+    assert len(agents) == 100 and type(agents[0].policy).__name__ == "GA3CCADRLPolicy"
+    assert np.allclose([a._case_row()[0][:6] for a in agents], want)
+    envtools.default()
