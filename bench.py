@@ -164,7 +164,8 @@ def env_api_rates(E, N, steps, torch, dev):
             env = CollisionAvoidanceEnv(num_envs=E, device=str(dev), **kw)
             env.set_fixture_suite(N)
             env.reset()
-            for _ in range(128):
+            ring = env._sim._la["n"] if env._sim._la is not None else 0
+            for _ in range(128 + 2 * ring):   # (two whole rings: the allocator then holds both blocks the fresh rings alternate between)
                 env.step(None)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -174,10 +175,10 @@ def env_api_rates(E, N, steps, torch, dev):
             dt = time.perf_counter() - t0
             out[name] = {"value": E * N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6}
             if name == "lookahead":
-                out[name]["ring"] = env.lookahead
+                out[name]["ring"] = env._sim._la["n"]
             del env
-        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; lookahead = the default (ring of "
-                       "CollisionAvoidanceEnv.LOOKAHEAD_DEFAULT steps per launch), single_launch = lookahead=0, fresh obs / reward / "
+        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; lookahead = the default (the longest ring "
+                       "CollisionAvoidanceEnv.LOOKAHEAD_BYTES of outputs allow, at most LOOKAHEAD_MAX steps per launch), single_launch = lookahead=0, fresh obs / reward / "
                        "game_over tensors per step, zero_copy = the persistent device buffers (one launch per step)" % (E, steps))
     except Exception as e:  # noqa: BLE001 -- an extra must never take the bench line down
         out["error"] = repr(e)

@@ -74,7 +74,7 @@ class CaNet(C.Structure):
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
            "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes",
-           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack", "cagpu_rollout_ring", "cagpu_debug_copy8")
+           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack", "cagpu_rollout_ring", "cagpu_ring_snapshots", "cagpu_debug_copy8")
 
 _lib = None
 
@@ -102,7 +102,8 @@ def lib():
     L.cagpu_reset.argtypes = [PP, PS, PO, _P, _P, _P, _P]
     L.cagpu_step.argtypes = [PP, PS, PO, _P, PA, _P]
     L.cagpu_rollout.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
-    L.cagpu_rollout_ring.argtypes = [PP, PS, PO, _P, PA, C.c_int32, _P]
+    L.cagpu_rollout_ring.argtypes = [PP, PS, PO, _P, PA, C.c_int32, C.c_int64, _P]
+    L.cagpu_ring_snapshots.argtypes = [PP, PS, PO, PA, C.c_int32]
     L.cagpu_debug_copy8.argtypes = [C.c_int64, _P, _P, _P]
     L.cagpu_step_map.argtypes = [PP, PS, PO, _P, PA, C.POINTER(CaMap), _P]
     L.cagpu_laserscan.argtypes = [PP, PS, C.POINTER(CaMap), C.POINTER(CaScan), _P]

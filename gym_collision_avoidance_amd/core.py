@@ -424,7 +424,7 @@ class BatchedSim(object):
     def reset(self, cases, headings=None, mask=None):
         if self._la is not None:
             if mask is None:      # every env starts over: whatever the ring ran ahead is void, nothing to rewind to
-                self._la["slots"], self._la["t"] = None, self._la["n"]
+                self._la["slots"] = None
                 if not self._la["fresh"]:
                     self._la["ring"] = None
             else:
@@ -595,7 +595,7 @@ class BatchedSim(object):
         draws, no per-agent sensor variants (extra cagpu_observe launches), no static map (wall test + laser scan)."""
         return not (self._has_ga3c or self._rvo is not None or self._variants or self._map is not None)
 
-    def enable_lookahead(self, k, fresh=True):
+    def enable_lookahead(self, k, fresh=True, adaptive=False):
         """Serve step(None) from a ring of `k` steps computed ahead of time in ONE launch (cagpu_rollout_ring): with every
         policy internal a step needs nothing from the host (env_utils.py:45-52 passes None until the episode is over),
         so step_lookahead() hands out slot t of the ring and launches the next k steps when it runs dry -- the fused
@@ -604,43 +604,68 @@ class BatchedSim(object):
         reading `state`, a reset, an external action, a parameter change, the episode statistics -- goes through sync(),
         which rewinds (restore the snapshot taken before the launch, re-run the steps already handed out).
         fresh: every refill writes into a NEWLY allocated ring (what step_lookahead returned stays valid and belongs to
-        the caller); False: one persistent ring, a slot is overwritten k steps later.  k = 0: off."""
+        the caller); False: one persistent ring, a slot is overwritten k steps later.  k = 0: off.
+        adaptive: k is the LONGEST ring.  A rewind throws the rest of a ring away, so a caller who looks at the state (or
+        acts) every m steps should not pay for k: after a rewind at slot t the next ring is t steps long (at least 1 = one
+        launch per step), and every ring consumed to its end doubles the next one up to k."""
         self.sync()
         k = int(k)
         if k <= 0:
             self._la = None
             return
-        self._la = dict(n=k, t=k, slots=None, fresh=bool(fresh), ring=None, snap=torch.empty_like(self._slab), fills=0)
+        self._la = dict(n=k, cur=k, len=0, t=0, slots=None, fresh=bool(fresh), adaptive=bool(adaptive), ring=None,
+                        snap=torch.empty_like(self._slab), fills=0, rewinds=0, in_kernel={}, next=None, co=None)
 
     def _la_fill(self):
         la = self._la
         if not self.lookahead_ok():
             raise nat.CagpuError("step_lookahead: this batch needs work between two steps (GA3C-CADRL network, stochastic RVO "
                                  "draws, sensor variants or a static map) -- use step()")
-        k, E, N = la["n"], self.E, self.N
-        if la["fresh"] or la["ring"] is None:
+        if la["adaptive"] and la["slots"] is not None and la["t"] >= la["len"]:   # the last ring was used up: a longer one
+            la["cur"] = min(la["n"], 2 * la["cur"])
+        k, E, N = la["cur"], self.E, self.N
+
+        def new_ring(n):
             dev = self.device
-            la["ring"] = (torch.empty((k, E, N, self.W), dtype=torch.float32, device=dev),
-                          torch.empty((k, E, N), dtype=torch.float32, device=dev),
-                          torch.empty((k, E, N), dtype=torch.uint8, device=dev),
-                          torch.empty((k, E), dtype=torch.uint8, device=dev))
+            return (torch.empty((n, E, N, self.W), dtype=torch.float32, device=dev), torch.empty((n, E, N), dtype=torch.float32, device=dev),
+                    torch.empty((n, E, N), dtype=torch.uint8, device=dev), torch.empty((n, E), dtype=torch.uint8, device=dev))
+        if la["fresh"]:     # (the next ring's tensors were allocated behind the previous launch: off the path to this one)
+            nxt, la["next"] = la["next"], None
+            la["ring"] = nxt if (nxt is not None and nxt[0].shape[0] == k) else new_ring(k)
+        elif la["ring"] is None or la["ring"][0].shape[0] != k:
+            la["ring"] = new_ring(k)
         obs, rew, done, over = la["ring"]
-        la["snap"].copy_(self._slab)           # stream-ordered in front of the launch: the state BEFORE the k steps
-        co = nat.CaOut.from_buffer_copy(self._co)
+        co = la["co"]
+        if co is None:      # (the ring's own CaOut: the workspace of self._co, no actions / orca_vel record)
+            co = la["co"] = nat.CaOut.from_buffer_copy(self._co)
+            co.actions, co.orca_vel = None, None
         co.obs, co.rewards, co.done, co.game_over = obs.data_ptr(), rew.data_ptr(), done.data_ptr(), over.data_ptr()
-        co.actions, co.orca_vel = None, None
-        nat.check(self.lib.cagpu_rollout_ring(C.byref(self.p), C.byref(self._cs), C.byref(co), None,
-                                              None if self._ar is None else C.byref(self._ar), k, self._stream()))
+        ar = None if self._ar is None else C.byref(self._ar)
+        # the rewind point = the state BEFORE the k steps: stored by the pipelined n-step kernel itself as it loads its
+        # tiles (snapshot_delta: the snapshot slab has the state slab's layout); by one device copy in front of the launch
+        # for the other kernels
+        key = (k, self.p.sort_mode, self._ar is not None and bool(self._ar.reset_obs), bool(self._cs.next_action))
+        in_kernel = la["in_kernel"].get(key)   # (which kernel a ring call runs depends on exactly these)
+        if in_kernel is None:
+            in_kernel = la["in_kernel"][key] = self.lib.cagpu_ring_snapshots(C.byref(self.p), C.byref(self._cs), C.byref(co), ar, k) == 1
+        delta = 0
+        if in_kernel:
+            delta = la["snap"].data_ptr() - self._slab.data_ptr()
+        else:
+            la["snap"].copy_(self._slab)
+        nat.check(self.lib.cagpu_rollout_ring(C.byref(self.p), C.byref(self._cs), C.byref(co), None, ar, k, delta, self._stream()))
         # (the kernels write 0 / 1 bytes: reinterpreted as bool without a conversion kernel)
         la["slots"] = list(zip(obs.unbind(0), rew.unbind(0), done.view(torch.bool).unbind(0), over.view(torch.bool).unbind(0)))
-        la["t"] = 0
+        la["t"], la["len"] = 0, k
         la["fills"] += 1
+        if la["fresh"]:
+            la["next"] = new_ring(min(la["n"], 2 * k) if la["adaptive"] else k)
 
     def step_lookahead(self):
         """one step(None) served from the look-ahead ring -> (obs [E,N,W], rewards [E,N], done [E,N] bool, game_over [E] bool)"""
         la = self._la
         t = la["t"]
-        if t >= la["n"] or la["slots"] is None:
+        if la["slots"] is None or t >= la["len"]:
             self._la_fill()
             t = 0
         la["t"] = t + 1
@@ -654,9 +679,13 @@ class BatchedSim(object):
         la = self._la
         if la is None or la["slots"] is None:
             return
-        t, k = la["t"], la["n"]
+        t, k = la["t"], la["len"]
         obs, rew, done, over = la["ring"]
-        la["slots"], la["t"] = None, k
+        la["slots"] = None
+        if t < k:
+            la["rewinds"] += 1
+            if la["adaptive"]:     # the caller came back after t steps: that is how far the next ring looks ahead
+                la["cur"] = max(1, t)
         if not la["fresh"]:
             la["ring"] = None      # (the current outputs below live in it: the next fill must not overwrite them)
         if t > 0:                  # the outputs of the last step handed out are the simulator's current outputs

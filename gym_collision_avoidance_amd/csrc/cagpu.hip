@@ -72,6 +72,8 @@ struct KArgs {
   // the slots of the observation block (E N W), of the per-agent outputs (E N; x 2 for the action pairs) and of game_over (E);
   // all 0 everywhere else (every step writes the same buffers)
   int64_t ring_obs, ring_agent, ring_env;
+  // cagpu_rollout_ring: != 0: the pipelined n-step kernel also stores the state it starts from at (address + snap_delta)
+  int64_t snap_delta;
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
 };
 
@@ -2036,7 +2038,8 @@ int cagpu_reset(const CaParams* p, const CaState* s, const CaOut* o, const doubl
 }
 
 static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const double* ext, const CaAutoReset* ar,
-                     int32_t n_steps, void* stream, const CaMap* map = nullptr, const bool ring = false) {
+                     int32_t n_steps, void* stream, const CaMap* map = nullptr, const bool ring = false,
+                     const int64_t snapshot_delta = 0, const bool query_snapshot = false) {
   int rc = check_params(p, s, o);
   if (rc) return rc;
   if (n_steps < 1) return fail(CA_EINVAL, "cagpu: n_steps must be >= 1%s");
@@ -2063,6 +2066,13 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
     k.ring_agent = static_cast<int64_t>(p->num_envs) * p->num_agents;
     k.ring_obs = k.ring_agent * (6 + 7 * p->max_obs);
     k.ring_env = p->num_envs;
+    // the in-kernel snapshot is the pipelined n-step kernel's (launch_pipe with n_steps > 1): every other form of the call
+    // leaves it to the caller (cagpu_ring_snapshots says which, from the same arguments)
+    const bool can = n_steps > 1 && pipe_eligible(k);
+    if (query_snapshot) return can ? 1 : 0;
+    if (snapshot_delta != 0 && !can)
+      return fail(CA_EUNSUPPORTED, "cagpu_rollout_ring: snapshot_delta needs the pipelined n-step kernel (cagpu_ring_snapshots() == 1 for these arguments)%s");
+    k.snap_delta = snapshot_delta;
   }
 #ifdef CAGPU_ABLATE
   if (const char* ab = std::getenv("CAGPU_ABLATE")) k.ablate = std::atoi(ab);
@@ -2240,8 +2250,12 @@ int cagpu_rollout(const CaParams* p, const CaState* s, const CaOut* o, const dou
 }
 
 int cagpu_rollout_ring(const CaParams* p, const CaState* s, const CaOut* o, const double* ext_actions, const CaAutoReset* ar,
-                       int32_t n_steps, void* stream) {
-  return step_impl(p, s, o, ext_actions, ar, n_steps, stream, nullptr, true);
+                       int32_t n_steps, int64_t snapshot_delta, void* stream) {
+  return step_impl(p, s, o, ext_actions, ar, n_steps, stream, nullptr, true, snapshot_delta);
+}
+
+int cagpu_ring_snapshots(const CaParams* p, const CaState* s, const CaOut* o, const CaAutoReset* ar, int32_t n_steps) {
+  return step_impl(p, s, o, nullptr, ar, n_steps, nullptr, nullptr, true, 0, true);
 }
 
 int cagpu_plan(const CaParams* p, const CaState* s, void* stream) {

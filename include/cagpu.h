@@ -350,9 +350,19 @@ int cagpu_rollout(const CaParams *p, const CaState *s, const CaOut *o, const dou
  *   o->actions / o->orca_vel (if given) [n_steps, E, N, 2].
  * State, statistics and auto-resets are those of cagpu_rollout(n_steps) -- i.e. of n_steps cagpu_step calls, bit for bit
  * (tests/test_gpu_ring.py).  Like cagpu_rollout it takes no per-step inputs (CaState.rvo_collab / rvo_heading_noise /
- * ext_state must be NULL: CA_EINVAL; ext_actions, if any, are held constant). */
+ * ext_state must be NULL: CA_EINVAL; ext_actions, if any, are held constant).
+ * snapshot_delta (bytes; 0 = none): the REWIND POINT.  A caller that runs ahead must be able to go back (an action arrives
+ * for step t < n_steps: restore the state the call started from, cagpu_rollout(t), go on one step at a time).  With all state
+ * arrays of `s` in ONE allocation and a second allocation of the same layout snapshot_delta bytes away, the kernel itself
+ * stores every state element it loads at its start -- all of `s` that a step reads or writes, env_stats included -- at
+ * (its address + snapshot_delta): when the call has run, the second allocation holds the state BEFORE the call.  Only the
+ * pipelined n-step kernel does this (cagpu_ring_snapshots() says whether a call with these arguments would); otherwise
+ * CA_EUNSUPPORTED and the caller copies the state itself ahead of the call. */
 int cagpu_rollout_ring(const CaParams *p, const CaState *s, const CaOut *o, const double *ext_actions,
-                       const CaAutoReset *ar, int32_t n_steps, void *stream);
+                       const CaAutoReset *ar, int32_t n_steps, int64_t snapshot_delta, void *stream);
+/* 1: cagpu_rollout_ring with these arguments runs the kernel that takes the snapshot itself (snapshot_delta != 0 accepted);
+ * 0: it does not; < 0: the arguments are invalid (CA_E*).  Host-only, launches nothing. */
+int cagpu_ring_snapshots(const CaParams *p, const CaState *s, const CaOut *o, const CaAutoReset *ar, int32_t n_steps);
 
 /* The policy query of the NEXT step ahead of time (collision_avoidance_env.py:305-323 for the built-in RVO policy):
  * fills s->next_action from the CURRENT state and sets CA_PLAN_VALID, without stepping.  cagpu_step / cagpu_rollout keep

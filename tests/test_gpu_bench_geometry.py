@@ -77,8 +77,11 @@ class Block(object):
             if n == "heading":          # an angle: compared modulo 2 pi (see tests/test_gpu_parity.py::_compare)
                 d = np.abs((a - b + np.pi) % (2 * np.pi) - np.pi)
                 assert d.size == 0 or d.max() <= TOL, "heading %s: %g" % (what, d.max())
-            elif n == "turning_dir":    # branches on the sign of a heading that may sit on the wrap boundary
-                assert (np.abs(a - b) > TOL).mean() <= 0.01 if a.size else True, "turning_dir " + what
+            elif n == "turning_dir":    # branches on the sign of a heading that may sit on the wrap boundary or at 0
+                bad = np.abs(a - b) > TOL
+                ho, hg = o.s["heading"][ra], g.state["heading"][sl].cpu().numpy().reshape(-1)[ra]
+                edge = (np.abs(ho) < 1e-7) | (np.abs(np.abs(ho) - np.pi) < 1e-7) | (np.abs(hg) < 1e-7) | (np.abs(np.abs(hg) - np.pi) < 1e-7)
+                assert not (bad & ~edge).any(), "turning_dir %s: differs away from a sign change of the heading" % what
             else:
                 np.testing.assert_allclose(a, b, rtol=0, atol=TOL, err_msg=n + " " + what)
         gobs = g.obs[sl].cpu().numpy().astype(np.float64)[rows]

@@ -85,6 +85,11 @@ def _compare(o, g, tol=TOL, what=""):
             # sits at the wrap boundary (+-pi: see above) or at 0 within an ulp may take the other branch -- a handful of agents
             # in the fuzzed configurations, none in the reference-recorded episodes (tests/test_gpu_env_api.py)
             bad = np.abs(gs[n] - o.s[n]) > tol
+            h = o.s["heading"]
+            on_edge = (np.abs(h) < 1e-7) | (np.abs(np.abs(h) - np.pi) < 1e-7) | \
+                      (np.abs(gs["heading"]) < 1e-7) | (np.abs(np.abs(gs["heading"]) - np.pi) < 1e-7)
+            assert not (bad & ~on_edge).any(), "turning_dir %s: %d of %d differ away from a sign change of the heading" % (
+                what, (bad & ~on_edge).sum(), bad.size)
             assert bad.mean() <= 0.01, "turning_dir %s: %d of %d differ" % (what, bad.sum(), bad.size)
             continue
         np.testing.assert_allclose(gs[n], o.s[n], rtol=0, atol=tol, err_msg=n + " " + what)

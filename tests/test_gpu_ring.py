@@ -75,7 +75,7 @@ def test_ring_slot_equals_single_launch_bit_for_bit_and_oracle_blocks(E, K):
     for view, copy in held:
         assert torch.equal(view, copy)
     assert torch.equal(a.episode_stats(), b.episode_stats())
-    assert b._la["fills"] >= 300 // K
+    assert b._la["fills"] >= 300 // K and b._la["rewinds"] >= 2 and list(b._la["in_kernel"].values()) == [True]
 
 
 def test_ring_c_abi_layout_and_argument_checks():
@@ -105,8 +105,26 @@ def test_ring_c_abi_layout_and_argument_checks():
         co = nat.CaOut.from_buffer_copy(b._co)
         for k_, v in ring.items():
             setattr(co, k_, v.data_ptr())
-        nat.check(b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, C.byref(b._ar), n, b._stream()))
+        # the rewind point: the pipelined n-step kernel stores the state it starts from itself (snapshot_delta); the others
+        # say so (cagpu_ring_snapshots) and refuse a delta
+        before = b._slab.clone()
+        snap = torch.full_like(b._slab, 0x5A)
+        can = b.lib.cagpu_ring_snapshots(C.byref(b.p), C.byref(b._cs), C.byref(co), C.byref(b._ar), n)
+        assert can == (1 if kern.startswith("ca_pipe_kernel") else 0), (N, can)
+        assert b.lib.cagpu_ring_snapshots(C.byref(b.p), C.byref(b._cs), C.byref(co), C.byref(b._ar), 1) == 0
+        delta = snap.data_ptr() - b._slab.data_ptr()
+        if not can:
+            assert b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, C.byref(b._ar), n, delta,
+                                            b._stream()) == nat.CA_EUNSUPPORTED
+        nat.check(b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, C.byref(b._ar), n, delta if can else 0,
+                                           b._stream()))
         assert nat.lib().cagpu_last_kernel().decode().startswith(kern), nat.lib().cagpu_last_kernel().decode()
+        if can:   # every state array of the slab, bit for bit as it was before the call (the padding between them aside)
+            for nme, t_ in b._state.items():
+                off = t_.data_ptr() - b._slab.data_ptr()
+                nb = t_.numel() * t_.element_size()
+                assert torch.equal(snap[off:off + nb], before[off:off + nb]), (N, nme)
+            assert not torch.equal(b._slab, before)
         for t in range(n):
             a.step()
             assert torch.equal(ring["obs"][t], a.obs) and torch.equal(ring["rewards"][t], a.rewards), (N, t)
@@ -122,7 +140,7 @@ def test_ring_c_abi_layout_and_argument_checks():
     b._cs.rvo_heading_noise = noise.data_ptr()
     try:
         assert b.lib.cagpu_rollout(C.byref(b.p), C.byref(b._cs), C.byref(b._co), None, None, 3, b._stream()) == nat.CA_EINVAL
-        assert b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, None, 1, b._stream()) == nat.CA_EINVAL
+        assert b.lib.cagpu_rollout_ring(C.byref(b.p), C.byref(b._cs), C.byref(co), None, None, 1, 0, b._stream()) == nat.CA_EINVAL
         assert b.lib.cagpu_step(C.byref(b.p), C.byref(b._cs), C.byref(b._co), None, None, b._stream()) == 0
     finally:
         b._cs.rvo_heading_noise = None
@@ -227,7 +245,9 @@ def test_env_api_serves_step_none_from_the_ring():
         env.reset()
         envs.append(env)
     ref, la = envs
-    assert la._la_on and not ref._la_on and la.lookahead == Env.LOOKAHEAD_DEFAULT and ref._sim._la is None
+    ring = la._sim._la
+    assert la._la_on and not ref._la_on and ref._sim._la is None
+    assert ring["n"] == Env.LOOKAHEAD_MAX == 256 and ring["adaptive"]      # (512 x 10: 1.4 MB per slot, the byte budget is far)
     kept = []
 
     def same(n, **kw):
@@ -239,18 +259,29 @@ def test_env_api_serves_step_none_from_the_ring():
             assert i0["which_agents_learning"] == i1["which_agents_learning"]
             assert g1.dtype == torch.bool and i1["which_agents_done"].dtype == torch.bool
             kept.append((o1, o1.clone()))
-    L = Env.LOOKAHEAD_DEFAULT
-    same(L + 13)
-    assert la._sim._la["fills"] == 2 and la._sim._la["t"] == 13
-    # reading an agent (a view of the device state) sees the step last handed out, not the end of the ring
+    same(256 + 13)
+    assert ring["fills"] == 2 and ring["t"] == 13 and ring["len"] == 256
+    # reading an agent (a view of the device state) sees the step last handed out, not the end of the ring -- and the ring
+    # adapts: the caller came back after 13 steps, so the next ring looks 13 steps ahead; used up, it doubles
     assert np.array_equal(ref.agents[3].pos_global_frame, la.agents[3].pos_global_frame)
     assert ref.agents[3].t == la.agents[3].t and ref.episode_step_number == la.episode_step_number
-    same(10)
-    same(3, dt=0.05)            # another dt: stepped one launch at a time, then back to the ring
+    assert ring["rewinds"] == 1 and ring["cur"] == 13 and ring["slots"] is None
+    same(13 + 26 + 5)
+    assert ring["fills"] == 5 and ring["len"] == 52 and ring["t"] == 5
+    same(3, dt=0.05)            # another dt: stepped one launch at a time (a rewind at slot 5), then back to the ring
+    assert ring["cur"] == 5
     same(40)
-    assert la._sim._la["slots"] is not None
+    assert ring["slots"] is not None
     assert ref.episode_stats() == la.episode_stats()
     same(7)
+    # a caller who looks at the state after EVERY step ends up with one launch per step, not with 256 steps per look
+    for _ in range(12):
+        same(1)
+        assert ref.agents[0].t == la.agents[0].t
+    assert ring["cur"] == 1 and ring["len"] == 1
+    launches = ring["fills"]
+    same(1 + 2 + 4)
+    assert ring["fills"] == launches + 3 and ring["len"] == 4
     for env in envs:
         env.reset()
     same(70)
