@@ -2105,7 +2105,7 @@ int cagpu_laserscan(const CaParams* p, const CaState* s, const CaMap* map, const
   k.p = *p; k.s = *s; k.m = *map; k.sc = *scan;
   const int N = p->num_agents;
   const size_t total = align16(scan_grid_words(map->rows, map->cols) * 4) + static_cast<size_t>(N) * (4 * 8 + 2 * 8 + 3 * 4 + 2 * 8 + 2 * 8 + 3 * 4 + 4 * 4) +
-                       static_cast<size_t>(scan->num_beams) * 16 + 256 * 4 + 32;
+                       static_cast<size_t>(scan->num_beams) * 16 + 256 * 4 + 32 + static_cast<size_t>(HIST_AG) * SCAN_NT;
   if (total > 160 * 1024) return fail(CA_EUNSUPPORTED, "cagpu_laserscan: map too large for the LDS bitmap%s");
   if (total > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel),
