@@ -295,3 +295,51 @@ def test_env_api_serves_step_none_from_the_ring():
     env.reset()
     assert not env._la_on
     envtools.default()
+
+
+@pytest.mark.parametrize("mode", ["ragged", "random_headings", "n6"])
+def test_ring_through_the_other_step_kernels_of_the_env_api(mode):
+    """the ring with batches the pipelined kernel does not take -- a ragged generated table (2 .. 10 agents per case:
+    CA_ABSENT slots), training-mode random headings at every auto-reset (no precomputed reset observations: ca_kernel's second
+    sensing pass; Philox headings are a function of (seed, env id, reset count, agent), so a rewind replays them) -- and
+    with another compiled-in agent count of the pipelined kernel (6 agents, 10-env tiles): env.step(None) with the default
+    ring == lookahead=0, step by step, through rewinds"""
+    Config, tc, Env = envtools.fresh("Bench10")
+    E = 300
+    envs = []
+    for la in (0, None):
+        env = Env(num_envs=E, lookahead=la)
+        if mode == "ragged":
+            sides = [{"num_agents": [0, 5], "side_length": [4, 5]}, {"num_agents": [5, 1 << 20], "side_length": [6, 8]}]
+            env.set_fixture_suite(10, "RVO", generate=dict(num_cases=400, seed=9, side_length=sides, num_agents=(2, 10)))
+        elif mode == "random_headings":
+            env.set_fixture_suite(10, "RVO", random_headings=True, heading_seed=77)
+        else:
+            env.set_fixture_suite(6, "RVO")
+        np.random.seed(3)
+        env.reset()
+        envs.append(env)
+    ref, la = envs
+    assert la._la_on and not ref._la_on
+    if mode == "random_headings":   # (reset() draws the initial headings from torch's generator: make both batches start alike)
+        for n in la._sim._state:
+            la._sim._state[n].copy_(ref._sim._state[n])
+        la._sim._obs.copy_(ref._sim._obs)
+    kernels = set()
+    for t in range(330):
+        o0, r0, g0, _, i0 = ref.step(None)
+        o1, r1, g1, _, i1 = la.step(None)
+        kernels.add(_mods()[0].lib().cagpu_last_kernel().decode().split(" grid")[0])
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(g0, g1), (mode, t)
+        assert torch.equal(i0["which_agents_done"], i1["which_agents_done"]), (mode, t)
+        if t in (50, 200):      # a rewind in the middle of a ring
+            assert ref.agents[0].t == la.agents[0].t
+    for n in F64 + ("flags", "step_num", "reset_count", "env_stats"):
+        a_, b_ = ref._sim.state[n], la._sim.state[n]
+        if n == "flags":
+            a_, b_ = a_ & ~_mods()[0].PLAN_VALID, b_ & ~_mods()[0].PLAN_VALID
+        assert torch.equal(a_, b_), (mode, n)
+    assert ref.episode_stats() == la.episode_stats() and ref.episode_stats()["episodes"] > E
+    want = {"n6": "ca_pipe_kernel<6, 10, true>", "ragged": "ca_pipe_kernel<10, 4, true>", "random_headings": "ca_kernel<256"}[mode]
+    assert any(k_.startswith(want) for k_ in kernels), kernels
+    envtools.default()
