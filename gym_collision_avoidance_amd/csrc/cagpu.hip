@@ -1664,7 +1664,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 int check_params(const CaParams* p, const CaState* s, const CaOut* o) {
   if (!p || !s || !o) return fail(CA_EINVAL, "cagpu: NULL params/state/out%s");
   if (p->num_envs < 1 || p->num_agents < 1) return fail(CA_EINVAL, "cagpu: num_envs and num_agents must be >= 1%s");
-  if (p->num_agents > big::NT) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 256 is not supported (one thread per agent in the large-env kernel)%s");
+  if (p->num_agents > big::NT_MAX) return fail(CA_EUNSUPPORTED, "cagpu: num_agents > 1024 is not supported (one thread per agent in the large-env kernel, 1024 threads per workgroup)%s");
   if (p->num_agents > 64 && !o->workspace)
     return fail(CA_EINVAL, "cagpu: num_agents > 64 runs the large-env kernel, which needs CaOut.workspace (cagpu_workspace_bytes(p) bytes)%s");
   if (p->max_obs < 0) return fail(CA_EINVAL, "cagpu: max_obs < 0%s");
@@ -1918,11 +1918,26 @@ int launch_big(const KArgs& k0, hipStream_t st) {
   if (wgs > k.p.num_envs) wgs = k.p.num_envs;
   const int n_steps = (k.mode == MODE_STEP) ? k.n_steps : 1;
   k.n_steps = 1;
-  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_big_kernel grid=%ld threads=%d ws_per_wg=%zu mode=%d", wgs, big::NT, per,
+  const int nt = big::threads_for(N);
+  const size_t lds = big::lds_bytes(nt);
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_big_kernel grid=%ld threads=%d ws_per_wg=%zu mode=%d", wgs, nt, per,
                 k.mode);
+  if (nt == 1024) {  // 88 KB of LDS: above the default dynamic limit
+    static std::atomic<bool> raised[64];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (!raised[dev_id & 63].load(std::memory_order_relaxed)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&big::ca_big_kernel<1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      raised[dev_id & 63].store(true, std::memory_order_relaxed);
+    }
+  }
   for (int s = 0; s < n_steps; ++s) {
-    hipLaunchKernelGGL(big::ca_big_kernel, dim3(static_cast<unsigned>(wgs)), dim3(big::NT), 0, st, k,
-                       static_cast<unsigned char*>(k.o.workspace), per);
+    unsigned char* wsp = static_cast<unsigned char*>(k.o.workspace);
+    if (nt == 256) hipLaunchKernelGGL(big::ca_big_kernel<256>, dim3(static_cast<unsigned>(wgs)), dim3(256), lds, st, k, wsp, per);
+    else if (nt == 512) hipLaunchKernelGGL(big::ca_big_kernel<512>, dim3(static_cast<unsigned>(wgs)), dim3(512), lds, st, k, wsp, per);
+    else hipLaunchKernelGGL(big::ca_big_kernel<1024>, dim3(static_cast<unsigned>(wgs)), dim3(1024), lds, st, k, wsp, per);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
     ring_advance(k);
@@ -2350,8 +2365,10 @@ int cagpu_ga3c_pack(const CaNet* net, void* packed, uint64_t bytes, void* stream
 }
 
 uint64_t cagpu_workspace_bytes(const CaParams* p) {
-  if (!p || p->num_agents <= 64 || p->num_agents > big::NT || p->num_envs < 1) return 0;
-  long wgs = 2L * device_cus();   // two resident workgroups per CU keep the device busy; more only cost memory
+  if (!p || p->num_agents <= 64 || p->num_agents > big::NT_MAX || p->num_envs < 1) return 0;
+  // two resident workgroups per CU keep the device busy (one above 256 agents: 8 / 16 waves and up to 88 KB of LDS each);
+  // more only cost memory (a share is 15 MB at 512 agents, 63 MB at 1024)
+  long wgs = (p->num_agents <= 256 ? 2L : 1L) * device_cus();
   if (wgs < 1) wgs = 512;
   if (wgs > p->num_envs) wgs = p->num_envs;
   return static_cast<uint64_t>(wgs) * big::ws_bytes_per_wg(p->num_agents);

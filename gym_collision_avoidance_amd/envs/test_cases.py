@@ -192,7 +192,7 @@ def make_testcase_huge(num_test_cases=1, num_agents=100, side_length=25, speed_b
     """[num_test_cases, num_agents, 6] crowd scenarios (test_cases.py:914-976): per agent a speed and a radius, then a start
     at least 2 m (surface to surface) from every earlier START and a goal at least 2 m from every earlier GOAL and 5 m from
     its own start, all rejection-sampled from the square [-side_length, side_length]^2.  Same np.random draws, in the
-    same order, as the reference.  (Up to 64 agents an env is one workgroup tile of the step kernels; 65 .. 256 agents run the
+    same order, as the reference.  (Up to 64 agents an env is one workgroup tile of the step kernels; 65 .. 1024 agents run the
     one-thread-per-agent kernel of csrc/cagpu_big.inc over CaOut.workspace -- DESIGN.md section 3c.)"""
     cases = np.empty((num_test_cases, num_agents, 6))
     for c in cases:

@@ -171,7 +171,8 @@ typedef struct CaOut {
   void *workspace;   /* device scratch for envs with MORE THAN 64 AGENTS, or NULL.  Up to 64 agents an env is one workgroup tile
                         and every per-(agent, other) quantity lives in LDS; beyond that (the reference's make_testcase_huge /
                         get_testcase_huge, test_cases.py:914-1018: 100 agents) the step runs a one-thread-per-agent kernel
-                        (num_agents <= 256) whose per-pair columns live here.  cagpu_workspace_bytes(p) says how much. */
+                        (num_agents <= 1024: workgroups of 256 / 512 / 1024 threads) whose per-pair columns live here.
+                        cagpu_workspace_bytes(p) says how much. */
   uint64_t workspace_bytes;
 } CaOut;
 
@@ -387,8 +388,9 @@ int cagpu_orca(int32_t num_envs, int32_t num_agents, const float *pos, const flo
 int cagpu_observe(const CaParams *p, const CaState *s, const CaOut *o, void *stream);
 
 /* Bytes of CaOut.workspace the step / reset / observe / rollout calls want for these parameters: 0 up to 64 agents per env,
- * otherwise one share (15 360 B x num_agents) per workgroup of the large-env kernel, for min(num_envs, 2 x CUs) workgroups
- * (a smaller workspace works too: fewer workgroups walk the envs).  Host-only call. */
+ * otherwise one share (60 B x threads x num_agents; threads = 256 / 512 / 1024 for up to 256 / 512 / 1024 agents) per
+ * workgroup of the large-env kernel, for min(num_envs, 2 x CUs) workgroups (1 x CUs above 256 agents); a smaller workspace
+ * works too: fewer workgroups walk the envs.  Host-only call. */
 uint64_t cagpu_workspace_bytes(const CaParams *p);
 
 /* Device-side fault word of the CURRENT device (synchronises it): bit 0 = a bounded hand-over poll inside the pipelined

@@ -73,7 +73,7 @@ def test_bad_arguments_are_loud_errors_not_crashes():
     lib = nat.lib()
     assert lib.cagpu_step(None, None, None, None, None, None) == nat.CA_EINVAL
     assert b"NULL" in lib.cagpu_last_error()
-    p = core.make_params(4, 300)     # beyond the large-env kernel's one thread per agent
+    p = core.make_params(4, 1300)    # beyond the large-env kernel's one thread per agent (1024 = the largest workgroup)
     s, o = nat.CaState(), nat.CaOut()
     assert lib.cagpu_observe(ctypes.byref(p), ctypes.byref(s), ctypes.byref(o), None) == nat.CA_EUNSUPPORTED
     p = core.make_params(4, 70)      # more than 64 agents: the large-env kernel wants its workspace
