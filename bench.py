@@ -165,19 +165,22 @@ def env_api_rates(E, N, steps, torch, dev):
             env.set_fixture_suite(N)
             env.reset()
             ring = env._sim._la["n"] if env._sim._la is not None else 0
-            for _ in range(128 + 2 * ring):   # (two whole rings: the allocator then holds both blocks the fresh rings alternate between)
+            # (the ring variant: warm up over two WHOLE rings -- the allocator then holds the blocks the fresh rings alternate
+            # between -- and time whole rings, so that exactly the steps that are served are computed inside the clock)
+            n_t = max(2, steps // ring) * ring if ring else steps
+            for _ in range(2 * ring if ring else 128):
                 env.step(None)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(n_t):
                 env.step(None)
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
-            out[name] = {"value": E * N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6}
+            out[name] = {"value": E * N * n_t / dt, "unit": "agent-steps/s", "us_per_step": dt / n_t * 1e6, "steps": n_t}
             if name == "lookahead":
-                out[name]["ring"] = env._sim._la["n"]
+                out[name]["ring"] = ring
             del env
-        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), %d steps, host wall clock; lookahead = the default (the longest ring "
+        out["note"] = ("CollisionAvoidanceEnv(num_envs=%d).step(None), ~%d steps (whole rings), host wall clock; lookahead = the default (the longest ring "
                        "CollisionAvoidanceEnv.LOOKAHEAD_BYTES of outputs allow, at most LOOKAHEAD_MAX steps per launch), single_launch = lookahead=0, fresh obs / reward / "
                        "game_over tensors per step, zero_copy = the persistent device buffers (one launch per step)" % (E, steps))
     except Exception as e:  # noqa: BLE001 -- an extra must never take the bench line down

@@ -422,13 +422,8 @@ class BatchedSim(object):
 
     # ---------------------------------------------------------------- the C-ABI calls
     def reset(self, cases, headings=None, mask=None):
-        if self._la is not None:
-            if mask is None:      # every env starts over: whatever the ring ran ahead is void, nothing to rewind to
-                self._la["slots"] = None
-                if not self._la["fresh"]:
-                    self._la["ring"] = None
-            else:
-                self.sync()
+        self.sync()   # (a ring that ran ahead is rewound even for a reset of EVERY env: env_stats outlive a reset and must not
+        #                hold episodes of steps that were never handed out)
         if self.fresh_outputs:   # the tensors the last step() handed out belong to their holder: never written again
             self._new_outputs(keep=mask is not None)
         c = self._dev(cases, torch.float64)

@@ -218,7 +218,8 @@ def test_sync_rewinds_for_everything_that_needs_the_current_step():
     run(18)
     assert torch.equal(a.episode_stats(), b.episode_stats())
     run(3)
-    both(lambda s: s.reset_from_table())     # a full reset drops the ring without a rewind
+    both(lambda s: s.reset_from_table())     # a full reset: the ring is rewound first (env_stats outlive the reset)
+    assert torch.equal(a.episode_stats(), b.episode_stats())
     run(40)
     _same_state(a, b, "at the end")
     b.enable_lookahead(0)
