@@ -131,11 +131,21 @@ class BatchedSim(object):
     # ---------------------------------------------------------------- what the outside reads
     # `state` and the four outputs are those of the step last handed out: reading them goes through sync(), which rewinds a
     # look-ahead ring that has run ahead (a no-op without one); the methods of this class use the underscored names.
-    state = property(lambda self: (self.sync(), self._state)[1])
-    obs = property(lambda self: (self.sync(), self._obs)[1], lambda self, v: setattr(self, "_obs", v))
-    rewards = property(lambda self: (self.sync(), self._rewards)[1], lambda self, v: setattr(self, "_rewards", v))
-    done = property(lambda self: (self.sync(), self._done)[1], lambda self, v: setattr(self, "_done", v))
-    game_over = property(lambda self: (self.sync(), self._game_over)[1], lambda self, v: setattr(self, "_game_over", v))
+    @property
+    def state(self):
+        self.sync()
+        return self._state
+
+    def _synced(name):   # noqa: N805 -- builds the four output properties
+        def get(self):
+            self.sync()
+            return getattr(self, name)
+
+        def put(self, value):
+            setattr(self, name, value)
+        return property(get, put)
+    obs, rewards, done, game_over = _synced("_obs"), _synced("_rewards"), _synced("_done"), _synced("_game_over")
+    del _synced
 
     # ---------------------------------------------------------------- plumbing
     def _stream(self):
