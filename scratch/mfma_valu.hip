@@ -1,0 +1,183 @@
+// scratch/mfma_valu.hip -- can the matrix pipe of a SIMD run beside that SIMD's VALU work?  The question behind the GA3C-CADRL
+// kernel's "matrix pipe 50 % busy + VALU 46 % busy, next to nothing overlapped" (DESIGN.md section 9): its LSTM step is, per wave
+// and row block, 56 MFMAs (48 x v_mfma_f32_16x16x32_bf16 + 8 x v_mfma_f32_16x16x4_f32) followed by ~133 VALU / transcendental
+// instructions that depend on them, with two waves (of two workgroups) per SIMD.
+// One workgroup of 512 threads per CU (8 waves = 2 per SIMD; role A = waves 0-3, role B = waves 4-7), every wave times its
+// own stream with s_memtime; the table gives cycles per wave for
+//   M alone, V alone         one wave per SIMD runs the MFMA burst / the VALU burst
+//   M | V                    wave A the MFMA burst, wave B of the same SIMD the VALU burst            (cross-wave overlap)
+//   M | M, V | V             both waves the same class                                                 (sharing)
+//   MV interleaved           ONE wave: an MFMA, then K independent VALU instructions, repeated         (in-wave overlap)
+//   [M..][V..] one wave      ONE wave: the burst of 56 MFMAs, then the burst of 133 VALU (independent of them)
+//   [M..][V..] x2 in phase / out of phase    two waves per SIMD run bursts; B starts with its VALU burst when out of phase
+// build: hipcc --offload-arch=gfx950 -O2 scratch/mfma_valu.hip -o scratch/mfma_valu ; run on the GPU box
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+struct St {
+  f32x4 acc[4];
+  float x[8];
+  u32x4 a, b;
+  float c;
+};
+
+template <int N4>  // 4 N4 bf16 MFMAs on four independent accumulators
+__device__ __forceinline__ void mburst(St& s) {
+#pragma unroll
+  for (int i = 0; i < N4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s.a), __builtin_bit_cast(bf16x8, s.b), s.acc[c], 0, 0, 0);
+  FENCE();
+}
+template <int N4>  // 4 N4 f32 MFMAs (16x16x4)
+__device__ __forceinline__ void mburst_f32(St& s) {
+#pragma unroll
+  for (int i = 0; i < N4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.c, s.x[c], s.acc[c], 0, 0, 0);
+  FENCE();
+}
+template <int N8, bool TRANS = false>  // 8 N8 VALU instructions on eight independent chains
+__device__ __forceinline__ void vburst(St& s) {
+#pragma unroll
+  for (int i = 0; i < N8; ++i) {
+    if (TRANS && (i % 3) == 2)
+      asm volatile("v_exp_f32 %0, %0\nv_exp_f32 %1, %1\nv_exp_f32 %2, %2\nv_exp_f32 %3, %3\nv_exp_f32 %4, %4\nv_exp_f32 %5, %5\nv_exp_f32 %6, %6\nv_exp_f32 %7, %7"
+                   : "+v"(s.x[0]), "+v"(s.x[1]), "+v"(s.x[2]), "+v"(s.x[3]), "+v"(s.x[4]), "+v"(s.x[5]), "+v"(s.x[6]), "+v"(s.x[7]));
+    else
+      asm volatile("v_fma_f32 %0, %0, %8, %8\nv_fma_f32 %1, %1, %8, %8\nv_fma_f32 %2, %2, %8, %8\nv_fma_f32 %3, %3, %8, %8\n"
+                   "v_fma_f32 %4, %4, %8, %8\nv_fma_f32 %5, %5, %8, %8\nv_fma_f32 %6, %6, %8, %8\nv_fma_f32 %7, %7, %8, %8"
+                   : "+v"(s.x[0]), "+v"(s.x[1]), "+v"(s.x[2]), "+v"(s.x[3]), "+v"(s.x[4]), "+v"(s.x[5]), "+v"(s.x[6]), "+v"(s.x[7])
+                   : "v"(s.c));
+  }
+  FENCE();
+}
+template <int K>  // one bf16 MFMA, then K independent VALU instructions
+__device__ __forceinline__ void interleaved(St& s, int c) {
+  s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s.a), __builtin_bit_cast(bf16x8, s.b), s.acc[c], 0, 0, 0);
+  FENCE();
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[k & 7]) : "v"(s.c));
+  FENCE();
+}
+
+enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, NMODES };
+static const char* kName[NMODES] = {
+    "M alone (A: 56 bf16 MFMA / iter)", "V alone (B: 136 v_fma / iter)", "M | V (A MFMA, B VALU)", "M | M", "V | V",
+    "one wave: MFMA + 1 VALU, x56", "one wave: MFMA + 2 VALU, x56", "one wave: MFMA + 3 VALU, x56", "one wave: MFMA + 4 VALU, x56",
+    "one wave: [56 MFMA][136 VALU]", "two waves in phase: [56 MFMA][136 VALU]", "two waves out of phase", "in phase, a third of the VALU v_exp",
+    "out of phase, a third v_exp", "MF alone (A: 56 f32 16x16x4 MFMA / iter)", "MF | V",
+    "two waves: MFMA + 2 VALU, x56", "two waves: MFMA + 3 VALU, x56", "two waves: (MFMA + 2 VALU) x56 + 24 VALU (8 v_exp)"};
+
+__global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int iters, int mode, float seed) {
+  extern __shared__ unsigned char pad[];  // (the dynamic LDS size keeps it at one workgroup per CU)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool roleA = wv < 4;
+  St s;
+  for (int c = 0; c < 4; ++c) s.acc[c] = f32x4{seed, seed, seed, seed};
+  for (int k = 0; k < 8; ++k) s.x[k] = seed + k;
+  s.a = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  s.b = s.a;
+  s.c = seed * 0.5f;
+  __syncthreads();
+  const long long t0 = clock64();
+  bool ran = true;
+  switch (mode) {
+    case M_ALONE: if (roleA) for (int i = 0; i < iters; ++i) mburst<14>(s); else ran = false; break;
+    case MF_ALONE: if (roleA) for (int i = 0; i < iters; ++i) mburst_f32<14>(s); else ran = false; break;
+    case V_ALONE: if (!roleA) for (int i = 0; i < iters; ++i) vburst<17>(s); else ran = false; break;
+    case M_V: if (roleA) for (int i = 0; i < iters; ++i) mburst<14>(s); else for (int i = 0; i < iters; ++i) vburst<17>(s); break;
+    case MF_V: if (roleA) for (int i = 0; i < iters; ++i) mburst_f32<14>(s); else for (int i = 0; i < iters; ++i) vburst<17>(s); break;
+    case M_M: for (int i = 0; i < iters; ++i) mburst<14>(s); break;
+    case V_V: for (int i = 0; i < iters; ++i) vburst<17>(s); break;
+    case IL1: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<1>(s, j & 3); } else ran = false; break;
+    case IL2: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<2>(s, j & 3); } else ran = false; break;
+    case IL3: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<3>(s, j & 3); } else ran = false; break;
+    case IL4: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<4>(s, j & 3); } else ran = false; break;
+    case IL2_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<2>(s, j & 3); } break;
+    case IL3_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<3>(s, j & 3); } break;
+    case IL2T_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<2>(s, j & 3); vburst<3, true>(s); } break;
+    case BURST1: if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } else ran = false; break;
+    case BURST2_IN: for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } break;
+    case BURST2_OUT:
+      if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); }
+      else for (int i = 0; i < iters; ++i) { vburst<17>(s); mburst<14>(s); }
+      break;
+    case BURST2T_IN: for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17, true>(s); } break;
+    case BURST2T_OUT:
+      if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17, true>(s); }
+      else for (int i = 0; i < iters; ++i) { vburst<17, true>(s); mburst<14>(s); }
+      break;
+  }
+  const long long t1 = clock64();
+  float sum = 0.f;
+  for (int c = 0; c < 4; ++c) sum += s.acc[c][0] + s.acc[c][1] + s.acc[c][2] + s.acc[c][3];
+  for (int k = 0; k < 8; ++k) sum += s.x[k];
+  if ((threadIdx.x & 63) == 0) {
+    out[blockIdx.x * 8 + wv] = ran ? (t1 - t0) : -1;
+    unsigned int hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    simd[blockIdx.x * 8 + wv] = (hw >> 4) & 3;
+  }
+  if (sum == 123.456f) out[0] = 0;
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 200;
+  const int G = 256;
+  long long* d_out;
+  int* d_simd;
+  hipMalloc(&d_out, G * 8 * sizeof(long long));
+  hipMalloc(&d_simd, G * 8 * sizeof(int));
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  std::vector<long long> h(G * 8);
+  std::vector<int> hs(G * 8);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) probe<<<G, 512, 100 * 1024>>>(d_out, d_simd, iters, M_M, 1.0f);
+  hipDeviceSynchronize();
+  printf("one 512-thread workgroup per CU, %d iterations; s_memtime ticks and event time per iteration, median over %d workgroups\n", iters, G);
+  printf("%-50s %12s %12s %12s\n", "mode", "A ticks/iter", "B ticks/iter", "event ns/iter");
+  for (int mode = 0; mode < NMODES; ++mode) {
+    probe<<<G, 512, 100 * 1024>>>(d_out, d_simd, iters, mode, 1.0f);
+    hipEventRecord(e0);
+    probe<<<G, 512, 100 * 1024>>>(d_out, d_simd, iters, mode, 1.0f);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), d_out, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    hipMemcpy(hs.data(), d_simd, hs.size() * sizeof(int), hipMemcpyDeviceToHost);
+    std::vector<double> a, b;
+    for (int g = 0; g < G; ++g)
+      for (int w = 0; w < 8; ++w) {
+        const long long v = h[g * 8 + w];
+        if (v >= 0) (w < 4 ? a : b).push_back(double(v) / iters);
+      }
+    auto med = [](std::vector<double>& v) {
+      if (v.empty()) return -1.0;
+      std::sort(v.begin(), v.end());
+      return v[v.size() / 2];
+    };
+    printf("%-50s %12.1f %12.1f %12.1f\n", kName[mode], med(a), med(b), ms * 1e6 / iters);
+    if (mode == 0) {
+      int same = 0;
+      for (int g = 0; g < G; ++g)
+        for (int w = 0; w < 4; ++w) same += hs[g * 8 + w] == hs[g * 8 + w + 4];
+      printf("    (waves w and w + 4 of a workgroup on the same SIMD: %d of %d pairs; SIMD of waves 0..7 in workgroup 0: %d %d %d %d %d %d %d %d)\n",
+             same, G * 4, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
+    }
+  }
+  return 0;
+}
