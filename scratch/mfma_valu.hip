@@ -62,6 +62,14 @@ __device__ __forceinline__ void vburst(St& s) {
   }
   FENCE();
 }
+template <int K>  // one f32 16x16x4 MFMA, then K independent VALU instructions
+__device__ __forceinline__ void interleaved_f32(St& s, int c) {
+  s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.c, s.x[c + 4], s.acc[c], 0, 0, 0);
+  FENCE();
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[k & 3]) : "v"(s.c));
+  FENCE();
+}
 template <int K>  // one bf16 MFMA, then K independent VALU instructions
 __device__ __forceinline__ void interleaved(St& s, int c) {
   s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s.a), __builtin_bit_cast(bf16x8, s.b), s.acc[c], 0, 0, 0);
@@ -71,13 +79,14 @@ __device__ __forceinline__ void interleaved(St& s, int c) {
   FENCE();
 }
 
-enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, NMODES };
+enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, ILF4, ILF4_X2, ILF0_X2, NMODES };
 static const char* kName[NMODES] = {
     "M alone (A: 56 bf16 MFMA / iter)", "V alone (B: 136 v_fma / iter)", "M | V (A MFMA, B VALU)", "M | M", "V | V",
     "one wave: MFMA + 1 VALU, x56", "one wave: MFMA + 2 VALU, x56", "one wave: MFMA + 3 VALU, x56", "one wave: MFMA + 4 VALU, x56",
     "one wave: [56 MFMA][136 VALU]", "two waves in phase: [56 MFMA][136 VALU]", "two waves out of phase", "in phase, a third of the VALU v_exp",
     "out of phase, a third v_exp", "MF alone (A: 56 f32 16x16x4 MFMA / iter)", "MF | V",
-    "two waves: MFMA + 2 VALU, x56", "two waves: MFMA + 3 VALU, x56", "two waves: (MFMA + 2 VALU) x56 + 24 VALU (8 v_exp)"};
+    "two waves: MFMA + 2 VALU, x56", "two waves: MFMA + 3 VALU, x56", "two waves: (MFMA + 2 VALU) x56 + 24 VALU (8 v_exp)",
+    "one wave: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA alone, x56"};
 
 __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int iters, int mode, float seed) {
   extern __shared__ unsigned char pad[];  // (the dynamic LDS size keeps it at one workgroup per CU)
@@ -107,6 +116,9 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int i
     case IL2_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<2>(s, j & 3); } break;
     case IL3_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<3>(s, j & 3); } break;
     case IL2T_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved<2>(s, j & 3); vburst<3, true>(s); } break;
+    case ILF4: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<4>(s, j & 3); } else ran = false; break;
+    case ILF4_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<4>(s, j & 3); } break;
+    case ILF0_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<0>(s, j & 3); } break;
     case BURST1: if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } else ran = false; break;
     case BURST2_IN: for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } break;
     case BURST2_OUT:
