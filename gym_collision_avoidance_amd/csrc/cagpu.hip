@@ -2176,13 +2176,18 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
                        net->net_index, epoch);
   }
   static_assert(ga3c::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+#if defined(CAGPU_GA3C_SOLO)   // timing experiment (scratch/ga3c_phases.py): one workgroup per CU, a wave has its SIMD to itself
+  constexpr size_t GA3C_LDS = 100 * 1024;
+#else
+  constexpr size_t GA3C_LDS = ga3c::LDS_BYTES;
+#endif
   static thread_local bool lds_raised[16] = {false};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   hipError_t e = hipSuccess;
   if (!lds_raised[dev_id & 15]) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ga3c::ga3c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(ga3c::LDS_BYTES));
+                            static_cast<int>(GA3C_LDS));
     if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: hipFuncSetAttribute: %s", hipGetErrorString(e));
     lds_raised[dev_id & 15] = true;
   }
@@ -2194,7 +2199,7 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
   // the tile height (64 / 48 / 32 rows) is chosen on the device from the number of live rows: the grid covers the worst
   // case (32-row tiles); workgroups beyond the last tile leave at once
   const unsigned grid = static_cast<unsigned>((k.B + 31) / 32);
-  hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), ga3c::LDS_BYTES, static_cast<hipStream_t>(stream), k);
+  hipLaunchKernelGGL(ga3c::ga3c_kernel, dim3(grid), dim3(ga3c::NT), GA3C_LDS, static_cast<hipStream_t>(stream), k);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
@@ -2350,14 +2355,14 @@ int cagpu_ga3c_pack(const CaNet* net, void* packed, uint64_t bytes, void* stream
     return fail(CA_EINVAL, "cagpu_ga3c_pack: NULL weight pointer%s");
   ga3c::u32x4* out = static_cast<ga3c::u32x4*>(packed);
   struct { const float* w; int row0, k_real, nkb, at; } jobs[4] = {
-      {net->lstm_kernel, 7, 64, 2, ga3c::PK_LSTM},     // rows 0..6 (x_t) stay float32
+      {net->lstm_kernel, 7, 64, 2, ga3c::PK_LSTM},     // rows 0..6 (x_t) and the bias: split by the kernel itself
       {net->layer1_kernel, 4, 64, 2, ga3c::PK_L1},     // rows 0..3 (host) stay float32
       {net->layer2_kernel, 0, 256, 8, ga3c::PK_L2},
       {net->fc1_kernel, 0, 256, 8, ga3c::PK_FC1}};
   for (const auto& j : jobs) {
     const int threads = j.nkb * 16 * 64;
     hipLaunchKernelGGL(ga3c::pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), j.w,
-                       j.row0, j.k_real, j.nkb, out + j.at);
+                       j.row0, j.k_real, j.nkb, out + j.at, j.at == ga3c::PK_LSTM ? 1 : 0);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_ga3c_pack: kernel launch failed: %s", hipGetErrorString(e));

@@ -34,7 +34,10 @@ for i, nm in enumerate(NAMES):
     print("  %-32s %12.0f  %5.1f %%" % (nm, buf[i] / n, 100.0 * buf[i] / tot))
 print("  per 64-row tile equivalent: %.0f cycles" % (tot / n / (rows / 64.0)))
 if buf[12]:
-    SEG = ["MFMA stages (+ cell updates between)", "last row block's cell update", "wait at barrier 1", "split + store h", "wait at barrier 2"]
+    if os.environ.get("FLOW_STAGE"):   # lstm_flow: stamps inside the stage of row block 1
+        SEG = ["-", "stage top -> first MFMA issued", "-> MFMA 8 issued", "-> MFMA 32 issued", "-> MFMA 56 issued"]
+    else:
+        SEG = ["MFMA stages (+ cell updates between)", "last row block's cell update", "wait at barrier 1", "split + store h", "wait at barrier 2"]
     print("LSTM step of wave 0, cycles per step (mean over %d tile-steps, %.2f row blocks per tile):" % (buf[12] / n, buf[13] / buf[12]))
     for k, nm in enumerate(SEG):
         print("  %-40s %8.0f" % (nm, buf[7 + k] / buf[12]))

@@ -2,7 +2,8 @@
 # PMC passes over ga3c_kernel (scratch/ga3c_loop.py: 150 steps of the config-3 workload, then 40 back-to-back launches at the
 # steady state's ~30 k live rows; the means below run over all 190 dispatches)
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-O=$R/gpurun_out/ga3c_pmc
+O=$R/gpurun_out/ga3c_pmc${1:+_$1}   # optional tag: one output directory per build (CAGPU_LIB selects the library)
+export PMC_OUT=$O
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P="env WARM=150 N=40 python $R/scratch/ga3c_loop.py"
@@ -12,7 +13,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS
 timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS SQ_WAIT_ANY --output-format csv -d $O/p3 -- $P > $O/p3.log 2>&1
 python - <<'PY'
 import csv, glob, os, collections
-O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/ga3c_pmc"
+O = os.environ["PMC_OUT"]
 for d in ("p1", "p2", "p3"):
     for f in glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)

@@ -28,6 +28,7 @@ struct St {
   float x[8];
   u32x4 a, b;
   float c;
+  float2 xp[4], cp;
 };
 
 template <int N4>  // 4 N4 bf16 MFMAs on four independent accumulators
@@ -62,6 +63,17 @@ __device__ __forceinline__ void vburst(St& s) {
   }
   FENCE();
 }
+template <int K, int KIND>  // one bf16 MFMA, then K independent v_exp_f32 (KIND 0) / v_pk_fma_f32 (KIND 1)
+__device__ __forceinline__ void interleaved_k(St& s, int c) {
+  s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s.a), __builtin_bit_cast(bf16x8, s.b), s.acc[c], 0, 0, 0);
+  FENCE();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (KIND == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[(k + c) & 7]));
+    else asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(s.xp[(k + c) & 3]) : "v"(s.cp));
+  }
+  FENCE();
+}
 template <int K>  // one f32 16x16x4 MFMA, then K independent VALU instructions
 __device__ __forceinline__ void interleaved_f32(St& s, int c) {
   s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.c, s.x[c + 4], s.acc[c], 0, 0, 0);
@@ -79,14 +91,16 @@ __device__ __forceinline__ void interleaved(St& s, int c) {
   FENCE();
 }
 
-enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, ILF4, ILF4_X2, ILF0_X2, NMODES };
+enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, ILF4, ILF4_X2, ILF0_X2, ILT1, ILT1_X2, ILT2, ILP1, ILP1_X2, ILP2_X2, NMODES };
 static const char* kName[NMODES] = {
     "M alone (A: 56 bf16 MFMA / iter)", "V alone (B: 136 v_fma / iter)", "M | V (A MFMA, B VALU)", "M | M", "V | V",
     "one wave: MFMA + 1 VALU, x56", "one wave: MFMA + 2 VALU, x56", "one wave: MFMA + 3 VALU, x56", "one wave: MFMA + 4 VALU, x56",
     "one wave: [56 MFMA][136 VALU]", "two waves in phase: [56 MFMA][136 VALU]", "two waves out of phase", "in phase, a third of the VALU v_exp",
     "out of phase, a third v_exp", "MF alone (A: 56 f32 16x16x4 MFMA / iter)", "MF | V",
     "two waves: MFMA + 2 VALU, x56", "two waves: MFMA + 3 VALU, x56", "two waves: (MFMA + 2 VALU) x56 + 24 VALU (8 v_exp)",
-    "one wave: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA alone, x56"};
+    "one wave: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA alone, x56",
+    "one wave: MFMA + 1 v_exp, x56", "two waves: MFMA + 1 v_exp, x56", "one wave: MFMA + 2 v_exp, x56",
+    "one wave: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 2 v_pk_fma, x56"};
 
 __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int iters, int mode, float seed) {
   extern __shared__ unsigned char pad[];  // (the dynamic LDS size keeps it at one workgroup per CU)
@@ -98,6 +112,8 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int i
   s.a = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   s.b = s.a;
   s.c = seed * 0.5f;
+  for (int k = 0; k < 4; ++k) s.xp[k] = make_float2(seed + k, seed - k);
+  s.cp = make_float2(seed * 0.5f, seed * 0.25f);
   __syncthreads();
   const long long t0 = clock64();
   bool ran = true;
@@ -119,6 +135,12 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int i
     case ILF4: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<4>(s, j & 3); } else ran = false; break;
     case ILF4_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<4>(s, j & 3); } break;
     case ILF0_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_f32<0>(s, j & 3); } break;
+    case ILT1: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 0>(s, j & 3); } else ran = false; break;
+    case ILT1_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 0>(s, j & 3); } break;
+    case ILT2: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<2, 0>(s, j & 3); } else ran = false; break;
+    case ILP1: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 1>(s, j & 3); } else ran = false; break;
+    case ILP1_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 1>(s, j & 3); } break;
+    case ILP2_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<2, 1>(s, j & 3); } break;
     case BURST1: if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } else ran = false; break;
     case BURST2_IN: for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } break;
     case BURST2_OUT:
@@ -135,6 +157,7 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int i
   float sum = 0.f;
   for (int c = 0; c < 4; ++c) sum += s.acc[c][0] + s.acc[c][1] + s.acc[c][2] + s.acc[c][3];
   for (int k = 0; k < 8; ++k) sum += s.x[k];
+  for (int k = 0; k < 4; ++k) sum += s.xp[k].x + s.xp[k].y;
   if ((threadIdx.x & 63) == 0) {
     out[blockIdx.x * 8 + wv] = ran ? (t1 - t0) : -1;
     unsigned int hw;

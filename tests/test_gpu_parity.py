@@ -771,7 +771,8 @@ def test_ga3c_split_operand_network_is_float32_accurate():
 
 def test_ga3c_pack_is_an_exact_split_and_required():
     """cagpu_ga3c_pack: every packed weight is hi + mid + lo EXACTLY (three bf16 planes, fragment order of
-    csrc/cagpu_ga3c.inc), rows past a matrix's K are zero; cagpu_ga3c refuses a CaNet without it"""
+    csrc/cagpu_ga3c.inc), rows past a matrix's K are zero; the LSTM kernel's columns carry the gates' 2^z scale (the float32
+    product with -log2 e, the j gate's with -2 log2 e: csrc/cagpu_ga3c.inc, struct Gate); cagpu_ga3c refuses a CaNet without it"""
     nat, core, orc = _mods()
     g = core.BatchedSim(core.make_params(4, 3, max_obs=19, sort_mode=1))
     g.set_plugins(nat.POL_GA3C_CADRL)
@@ -792,6 +793,8 @@ def test_ga3c_pack_is_an_exact_split_and_required():
             for cb in range(16):
                 k = row0 + kb * 32 + 8 * q[:, None] + np.arange(8)[None, :]    # [lane, e]
                 want = w[k, (cb * 16 + m)[:, None]]
+                if name == "lstm_kernel":
+                    want = want * np.float32(-2.88539008177792681 if cb // 4 == 1 else -1.44269504088896341)
                 p3 = blk[kb, cb]
                 total = (p3[0].astype(np.float64) + p3[1] + p3[2]).astype(np.float32)
                 assert np.array_equal(total, want), (name, kb, cb)
