@@ -38,9 +38,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.
 # GA3C-CADRL network, multiply-adds per query with all 19 LSTM steps live
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_bf16 / 32x32x16, dense (MI355X_MICROARCH.md)
 GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
-# of which on the bf16 matrix cores as SIX plane products each (float32 operands split exactly into three bf16 planes): the h
-# part of the LSTM, the h part of layer1, layer2, fullyconnected1; the rest (x_t, host inputs, logits) on the exact f32 MFMA
-GA3C_MACS_BF16 = 19 * 64 * 256 + 64 * 256 + 2 * 256 * 256
+# of which on the bf16 matrix cores as SIX plane products each (float32 operands split exactly into three bf16 planes): the
+# whole LSTM (round 5: x_t and the bias too -- K = 32 as four groups of 8, two MFMAs per gate), the h part of layer1, layer2,
+# fullyconnected1; the rest (layer1's host inputs, logits) on the exact f32 MFMA
+GA3C_MACS_BF16 = 19 * 71 * 256 + 64 * 256 + 2 * 256 * 256
 GA3C_PLANE_PRODUCTS = 6
 
 
@@ -209,8 +210,8 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
         flops = 2.0 * GA3C_MACS * rows
         out["metric"] = "agent-steps/sec at 4096 envs x 20 agents (GA3C-CADRL)"
         out["dtype"] = ("f32 network: float32 operands split exactly into three bf16 planes, 6 of the 9 plane products on the "
-                        "bf16 matrix cores (v_mfma_f32_16x16x32_bf16, f32 accumulate; a product within 2^-21), x_t / host inputs "
-                        "/ logits on the exact f32 MFMA; f64 simulator state")
+                        "bf16 matrix cores (v_mfma_f32_16x16x32_bf16, f32 accumulate; a product within 2^-21), layer1's host inputs "
+                        "and the logits on the exact f32 MFMA; f64 simulator state")
         out["config"]["workload"] = ("configs[2]: %d envs/GPU x %d agents, GA3CCADRLPolicy (IROS18 checkpoint, LSTM-64 + "
                                      "3 x FC-256, argmax of 11 actions) + UnicycleDynamics + OtherAgentsStatesSensor K=19 "
                                      "closest_last, fixture n20 (reference generator, seed 0), auto-reset; one cagpu_ga3c "
