@@ -296,15 +296,16 @@ int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const
  * device float [E,N,11], written for the same agents.  Arithmetic: float32 like the TF graph, on the BF16 matrix cores
  * (v_mfma_f32_16x16x32_bf16, f32 accumulate): both operands of every contraction are split exactly into three bf16 planes
  * (x = hi + mid + lo) and the six largest of the nine plane products are accumulated -- a product is off by less than
- * 2^-21 of itself (an f32 multiply: 2^-24); the x_t / host inputs and the logits layer run on the exact f32 MFMA
- * (v_mfma_f32_16x16x4_f32).  Logits agree with a float32 evaluation of the graph to ~1e-6 (tests: rtol 1e-4, atol 2e-4).
+ * 2^-21 of itself (an f32 multiply: 2^-24); layer1's four host inputs and the logits layer run on the exact f32 MFMA
+ * (v_mfma_f32_16x16x4_f32; the LSTM does not: that instruction holds the SIMD's VALU).  Logits agree with a float32 evaluation of the graph to ~1e-6 (tests: rtol 1e-4, atol 2e-4).
  * Needs net->packed (cagpu_ga3c_pack). */
 int cagpu_ga3c(const CaParams *p, const CaState *s, const float *obs, const CaNet *net, double *ext_actions,
                float *logits, void *stream);
 
 /* The size of CaNet.packed, and the one-time split of a checkpoint's weights into it: reads net->lstm_kernel,
  * layer1_kernel, layer2_kernel, fc1_kernel (device float32, the checkpoint's [in, out] layout) and writes `bytes` =
- * cagpu_ga3c_packed_bytes() bytes at `packed` (device, 16-byte aligned).  Replaces nothing in the reference (TF keeps its
+ * cagpu_ga3c_packed_bytes() bytes at `packed` (device, 16-byte aligned); the LSTM kernel's columns are stored multiplied (in
+ * float32) by -log2 e (gates i, f, o) / -2 log2 e (gate j): the kernel evaluates the gates as 1 / (1 + 2^z).  Replaces nothing in the reference (TF keeps its
  * variables in one layout); it is this library's equivalent of GA3CCADRLPolicy.initialize_network's checkpoint restore
  * (GA3CCADRLPolicy.py:23-47).  Call again after changing a weight array. */
 uint64_t cagpu_ga3c_packed_bytes(void);
