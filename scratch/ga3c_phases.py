@@ -28,11 +28,14 @@ for _ in range(n):
 torch.cuda.synchronize()
 lib.cagpu_debug_prof(buf, 0)
 rows = sim.ga3c_rows()
-tot = sum(buf[i] for i in range(7))
+tot = sum(buf[i] for i in range(7)) + buf[14] + buf[15]
 print("rows %d; cycles per launch summed over tiles, share" % rows)
 for i, nm in enumerate(NAMES):
     print("  %-32s %12.0f  %5.1f %%" % (nm, buf[i] / n, 100.0 * buf[i] / tot))
 print("  per 64-row tile equivalent: %.0f cycles" % (tot / n / (rows / 64.0)))
+if buf[14]:
+    print("  prologue in parts: start -> loads issued %.0f, -> first barrier passed %.0f, normalise + store %.0f (per launch, summed over tiles)"
+          % (buf[14] / n, buf[15] / n, buf[0] / n))
 if buf[12]:
     if os.environ.get("FLOW_STAGE"):   # lstm_flow: stamps inside the stage of row block 1
         SEG = ["-", "stage top -> first MFMA issued", "-> MFMA 8 issued", "-> MFMA 32 issued", "-> MFMA 56 issued"]
