@@ -769,23 +769,24 @@ def test_ga3c_split_operand_network_is_float32_accurate():
     # (a bf16-precision product would be off by ~1e-1 here: four orders of magnitude above the bound)
 
 
-def test_ga3c_pack_is_an_exact_split_and_required():
-    """cagpu_ga3c_pack: every packed weight is hi + mid + lo EXACTLY (three bf16 planes, fragment order of
-    csrc/cagpu_ga3c.inc), rows past a matrix's K are zero; the LSTM kernel's columns carry the gates' 2^z scale (the float32
-    product with -log2 e, the j gate's with -2 log2 e: csrc/cagpu_ga3c.inc, struct Gate); cagpu_ga3c refuses a CaNet without it"""
+def test_ga3c_pack_is_the_two_plane_split_and_required():
+    """cagpu_ga3c_pack: every packed weight is its two fp16 planes hi = fp16(w), lo = fp16(w - hi) (round to nearest, fp16
+    denormals kept; fragment order of csrc/cagpu_ga3c.inc), hi + lo within 2^-22 of w, rows past a matrix's K are zero; the
+    LSTM kernel's columns carry the gates' 2^z scale (the float32 product with -log2 e, the j gate's with -2 log2 e:
+    csrc/cagpu_ga3c.inc, struct Gate); cagpu_ga3c refuses a CaNet without it"""
     nat, core, orc = _mods()
     g = core.BatchedSim(core.make_params(4, 3, max_obs=19, sort_mode=1))
     g.set_plugins(nat.POL_GA3C_CADRL)
     g.load_ga3c()
     torch.cuda.synchronize()
     ts = g._net_tensors
-    pk = ts["packed"].cpu().numpy().view(np.uint16).reshape(-1, 3, 64, 8)     # [(kb, cb), plane, lane, e]
-    assert pk.shape[0] * 3 * 64 * 16 == int(g.lib.cagpu_ga3c_packed_bytes())
-    planes = (pk.astype(np.uint32) << 16).view(np.float32)                     # bf16 -> float32, exact
+    pk = ts["packed"].cpu().numpy().view(np.float16).reshape(-1, 2, 64, 8)     # [(kb, cb), plane, lane, e]
+    assert pk.shape[0] * 2 * 64 * 16 == int(g.lib.cagpu_ga3c_packed_bytes())
+    planes = pk.astype(np.float32)                                              # fp16 -> float32, exact
     at = 0
     for name, row0, nkb in (("lstm_kernel", 7, 2), ("layer1_kernel", 4, 2), ("layer2_kernel", 0, 8), ("fc1_kernel", 0, 8)):
         w = ts[name].cpu().numpy()
-        blk = planes[at:at + nkb * 16].reshape(nkb, 16, 3, 64, 8)
+        blk = planes[at:at + nkb * 16].reshape(nkb, 16, 2, 64, 8)
         at += nkb * 16
         lane = np.arange(64)
         m, q = lane & 15, lane >> 4
@@ -795,10 +796,11 @@ def test_ga3c_pack_is_an_exact_split_and_required():
                 want = w[k, (cb * 16 + m)[:, None]]
                 if name == "lstm_kernel":
                     want = want * np.float32(-2.88539008177792681 if cb // 4 == 1 else -1.44269504088896341)
-                p3 = blk[kb, cb]
-                total = (p3[0].astype(np.float64) + p3[1] + p3[2]).astype(np.float32)
-                assert np.array_equal(total, want), (name, kb, cb)
-                assert np.all(np.abs(p3[1]) <= np.abs(p3[0]) * 2.0 ** -7 + 1e-45) and np.all(np.abs(p3[2]) <= np.abs(p3[0]) * 2.0 ** -15 + 1e-45)
+                p2 = blk[kb, cb]
+                hi = want.astype(np.float16).astype(np.float32)
+                lo = (want - hi).astype(np.float16).astype(np.float32)
+                assert np.array_equal(p2[0], hi) and np.array_equal(p2[1], lo), (name, kb, cb)
+                assert np.all(np.abs((p2[0].astype(np.float64) + p2[1]) - want) <= np.abs(want) * 2.0 ** -22 + 3e-8)
     assert at == planes.shape[0]
     g._net.packed = None
     with pytest.raises(nat.CagpuError, match="packed"):
