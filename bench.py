@@ -36,13 +36,14 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md)
 # GA3C-CADRL network, multiply-adds per query with all 19 LSTM steps live
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_bf16 / 32x32x16, dense (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16 / _bf16 (and 32x32x16), dense (MI355X_MICROARCH.md)
 GA3C_MACS = 19 * 71 * 256 + 68 * 256 + 2 * 256 * 256 + 256 * 11
-# of which on the bf16 matrix cores as SIX plane products each (float32 operands split exactly into three bf16 planes): the
-# whole LSTM (round 5: x_t and the bias too -- K = 32 as four groups of 8, two MFMAs per gate), the h part of layer1, layer2,
-# fullyconnected1; the rest (layer1's host inputs, logits) on the exact f32 MFMA
+# of which on the f16 matrix cores as THREE plane products each (float32 operands as two fp16 planes, hi = fp16(x), lo =
+# fp16(x - hi): 22 of the 24 significant bits; rounds 2 - 4: three bf16 planes, six products): the whole LSTM (x_t and the bias
+# too -- K = 32 as four groups of 8, one MFMA per gate), the h part of layer1, layer2, fullyconnected1; the rest (layer1's host
+# inputs, logits) on the exact f32 MFMA
 GA3C_MACS_BF16 = 19 * 71 * 256 + 64 * 256 + 2 * 256 * 256
-GA3C_PLANE_PRODUCTS = 6
+GA3C_PLANE_PRODUCTS = 3
 
 
 def _profile_records(stem):
@@ -209,21 +210,21 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
         rows = sim.ga3c_rows()   # agents evaluated by the timed launches (live GA3C-CADRL agents, packed by cagpu_ga3c)
         flops = 2.0 * GA3C_MACS * rows
         out["metric"] = "agent-steps/sec at 4096 envs x 20 agents (GA3C-CADRL)"
-        out["dtype"] = ("f32 network: float32 operands split exactly into three bf16 planes, 6 of the 9 plane products on the "
-                        "bf16 matrix cores (v_mfma_f32_16x16x32_bf16, f32 accumulate; a product within 2^-21), layer1's host inputs "
+        out["dtype"] = ("f32 network: float32 operands as two fp16 planes (hi + lo = 22 significant bits, fp16 denormals kept), 3 of the 4 "
+                        "plane products on the f16 matrix cores (v_mfma_f32_16x16x32_f16, f32 accumulate; a product within 2^-21), layer1's host inputs "
                         "and the logits on the exact f32 MFMA; f64 simulator state")
         out["config"]["workload"] = ("configs[2]: %d envs/GPU x %d agents, GA3CCADRLPolicy (IROS18 checkpoint, LSTM-64 + "
                                      "3 x FC-256, argmax of 11 actions) + UnicycleDynamics + OtherAgentsStatesSensor K=19 "
                                      "closest_last, fixture n20 (reference generator, seed 0), auto-reset; one cagpu_ga3c "
                                      "+ one cagpu_step launch per step%s" % (E, N, "; FUSED sensing: the network kernel computes its "
                                      "observation rows from the state (obs = NULL)" if a.ga3c_fused else ""))
-        # the roofline of a float32 contraction done this way: every product costs six bf16 plane products
+        # the roofline of a float32 contraction done this way: every product costs three f16 plane products
         peak = BF16_MFMA_PEAK_TFLOPS / GA3C_PLANE_PRODUCTS
         issued = 2.0 * rows * (GA3C_MACS_BF16 * GA3C_PLANE_PRODUCTS) / infer_s / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": flops / infer_s / 1e12, "peak": peak,
                            "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / peak, "traffic": None,
-                           "peak_note": "bf16 dense MFMA peak (2500 TFLOP/s) / 6 plane products per float32 product",
-                           "issued_bf16_tflops": issued, "issued_frac_of_bf16_peak": issued / BF16_MFMA_PEAK_TFLOPS,
+                           "peak_note": "f16 dense MFMA peak (2500 TFLOP/s) / 3 plane products per float32 product (rounds 2 - 4: / 6)",
+                           "issued_f16_tflops": issued, "issued_frac_of_f16_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak": flops / infer_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
                            "kernel": "ga3c::ga3c_kernel", "avg_launch_us": infer_s * 1e6,
                            "algorithmic_flops_per_launch": flops, "macs_per_agent_query": GA3C_MACS,

@@ -307,7 +307,7 @@ class BatchedSim(object):
             ts[f] = torch.from_numpy(a).to(self.device)
         # scratch of cagpu_ga3c: the packed list of the agents that need an action this step (+ their count)
         ts["rows_scratch"] = torch.empty((self.E * self.N + 6,), dtype=torch.int32, device=self.device)
-        # the four big matrices as bf16 planes in matrix-core fragment order: split once per checkpoint on the device
+        # the four big matrices as fp16 planes in matrix-core fragment order: split once per checkpoint on the device
         ts["packed"] = torch.empty((int(self.lib.cagpu_ga3c_packed_bytes()),), dtype=torch.uint8, device=self.device)
         net = nat.CaNet(**{f: ts[f].data_ptr() for f in nat.NET_FIELDS + ("rows_scratch", "packed")})
         nat.check(self.lib.cagpu_ga3c_pack(C.byref(net), ts["packed"].data_ptr(), ts["packed"].numel(), self._stream()))

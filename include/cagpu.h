@@ -238,10 +238,10 @@ typedef struct CaNet {
    * distinct checkpoint (each writes its own agents' entries of ext_actions).  NULL: every live GA3C-CADRL agent. */
   const int32_t *agent_net;
   int32_t net_index, reserved0;
-  /* The four big weight matrices as bf16 planes in matrix-core fragment order: device buffer of cagpu_ga3c_packed_bytes()
+  /* The four big weight matrices as fp16 planes in matrix-core fragment order: device buffer of cagpu_ga3c_packed_bytes()
    * bytes (16-byte aligned), filled ONCE per checkpoint by cagpu_ga3c_pack() from the float32 arrays above (which cagpu_ga3c
    * still reads for the x_t / host inputs, the biases and the logits layer).  Required: cagpu_ga3c fails with CA_EINVAL
-   * without it.  The network computes on float32 operands split EXACTLY into three bf16 planes; see cagpu_ga3c. */
+   * without it.  The network computes on float32 operands carried as two fp16 planes (22 significant bits); see cagpu_ga3c. */
   const void *packed;
 } CaNet;
 
@@ -293,9 +293,10 @@ int cagpu_laserscan(const CaParams *p, const CaState *s, const CaMap *map, const
  * the kernel computes the ego-centric observation of every agent it evaluates from the state arrays itself
  * (OtherAgentsStatesSensor.sense + the observation assembly, with p->obs_clip / sort_mode / sensing_horizon), bit-identical to
  * the stored row; needs num_agents <= 32 and closest_first / closest_last sorting.  logits (nullable):
- * device float [E,N,11], written for the same agents.  Arithmetic: float32 like the TF graph, on the BF16 matrix cores
- * (v_mfma_f32_16x16x32_bf16, f32 accumulate): both operands of every contraction are split exactly into three bf16 planes
- * (x = hi + mid + lo) and the six largest of the nine plane products are accumulated -- a product is off by less than
+ * device float [E,N,11], written for the same agents.  Arithmetic: float32 like the TF graph, on the F16 matrix cores
+ * (v_mfma_f32_16x16x32_f16, f32 accumulate): both operands of every contraction are carried as two fp16 planes
+ * (x ~ hi + lo, hi = fp16(x), lo = fp16(x - hi): 22 of 24 significant bits, fp16 denormals kept) and three of the four
+ * plane products are accumulated -- a product is off by less than
  * 2^-21 of itself (an f32 multiply: 2^-24); layer1's four host inputs and the logits layer run on the exact f32 MFMA
  * (v_mfma_f32_16x16x4_f32; the LSTM does not: that instruction holds the SIMD's VALU).  Logits agree with a float32 evaluation of the graph to ~1e-6 (tests: rtol 1e-4, atol 2e-4).
  * Needs net->packed (cagpu_ga3c_pack). */
