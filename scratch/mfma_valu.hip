@@ -74,6 +74,17 @@ __device__ __forceinline__ void interleaved_k(St& s, int c) {
   }
   FENCE();
 }
+template <int KIND>  // the VALU-bound mix of the two-plane LSTM stage: one MFMA, two transcendentals, two plain (KIND 0/2) or one packed (1/3)
+__device__ __forceinline__ void mix(St& s, int c) {
+  s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s.a), __builtin_bit_cast(bf16x8, s.b), s.acc[c], 0, 0, 0);
+  FENCE();
+  asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[c]));
+  if (KIND == 0) { asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[c + 4])); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[(c + 1) & 3]) : "v"(s.c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[4 + ((c + 1) & 3)]) : "v"(s.c)); }
+  if (KIND == 1) { asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[c + 4])); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(s.xp[(c + 1) & 3]) : "v"(s.cp)); }
+  if (KIND == 2) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[(c + 1) & 3]) : "v"(s.c)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s.x[4 + ((c + 1) & 3)]) : "v"(s.c)); asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[c + 4])); }
+  if (KIND == 3) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(s.xp[(c + 1) & 3]) : "v"(s.cp)); asm volatile("v_exp_f32 %0, %0" : "+v"(s.x[c + 4])); }
+  FENCE();
+}
 template <int K>  // one f32 16x16x4 MFMA, then K independent VALU instructions
 __device__ __forceinline__ void interleaved_f32(St& s, int c) {
   s.acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.c, s.x[c + 4], s.acc[c], 0, 0, 0);
@@ -91,7 +102,7 @@ __device__ __forceinline__ void interleaved(St& s, int c) {
   FENCE();
 }
 
-enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, ILF4, ILF4_X2, ILF0_X2, ILT1, ILT1_X2, ILT2, ILP1, ILP1_X2, ILP2_X2, NMODES };
+enum Mode { M_ALONE, V_ALONE, M_V, M_M, V_V, IL1, IL2, IL3, IL4, BURST1, BURST2_IN, BURST2_OUT, BURST2T_IN, BURST2T_OUT, MF_ALONE, MF_V, IL2_X2, IL3_X2, IL2T_X2, ILF4, ILF4_X2, ILF0_X2, ILT1, ILT1_X2, ILT2, ILP1, ILP1_X2, ILP2_X2, MIX_S_X2, MIX_P_X2, MIX_S3_X2, MIX_P3_X2, NMODES };
 static const char* kName[NMODES] = {
     "M alone (A: 56 bf16 MFMA / iter)", "V alone (B: 136 v_fma / iter)", "M | V (A MFMA, B VALU)", "M | M", "V | V",
     "one wave: MFMA + 1 VALU, x56", "one wave: MFMA + 2 VALU, x56", "one wave: MFMA + 3 VALU, x56", "one wave: MFMA + 4 VALU, x56",
@@ -100,7 +111,9 @@ static const char* kName[NMODES] = {
     "two waves: MFMA + 2 VALU, x56", "two waves: MFMA + 3 VALU, x56", "two waves: (MFMA + 2 VALU) x56 + 24 VALU (8 v_exp)",
     "one wave: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA + 4 VALU, x56", "two waves: f32 MFMA alone, x56",
     "one wave: MFMA + 1 v_exp, x56", "two waves: MFMA + 1 v_exp, x56", "one wave: MFMA + 2 v_exp, x56",
-    "one wave: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 2 v_pk_fma, x56"};
+    "one wave: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 1 v_pk_fma, x56", "two waves: MFMA + 2 v_pk_fma, x56",
+    "two waves: (MFMA, v_exp, v_exp, v_fma, v_fma) x56", "two waves: (MFMA, v_exp, v_exp, v_pk_fma) x56",
+    "two waves: (MFMA, v_exp, v_fma, v_fma, v_exp) x56", "two waves: (MFMA, v_exp, v_pk_fma, v_exp) x56"};
 
 __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int iters, int mode, float seed) {
   extern __shared__ unsigned char pad[];  // (the dynamic LDS size keeps it at one workgroup per CU)
@@ -141,6 +154,10 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int* simd, int i
     case ILP1: if (roleA) for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 1>(s, j & 3); } else ran = false; break;
     case ILP1_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<1, 1>(s, j & 3); } break;
     case ILP2_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) interleaved_k<2, 1>(s, j & 3); } break;
+    case MIX_S_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) mix<0>(s, j & 3); } break;
+    case MIX_P_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) mix<1>(s, j & 3); } break;
+    case MIX_S3_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) mix<2>(s, j & 3); } break;
+    case MIX_P3_X2: for (int i = 0; i < iters; ++i) { _Pragma("unroll") for (int j = 0; j < 56; ++j) mix<3>(s, j & 3); } break;
     case BURST1: if (roleA) for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } else ran = false; break;
     case BURST2_IN: for (int i = 0; i < iters; ++i) { mburst<14>(s); vburst<17>(s); } break;
     case BURST2_OUT:

@@ -508,14 +508,15 @@ def test_carrl_fixture_family_and_huge_testcase():
 def test_ga3c_gate_micro_op_orders_are_schedules_of_the_cell_update():
     """csrc/cagpu_ga3c.inc places the LSTM's cell update by hand: GATE_ORDER / GATE_ORDER_SEL list the single-instruction
     micro-ops (4 step + element) in the order they are issued behind the MFMAs.  Whatever the order, it must be a
-    permutation that respects the update's data flow (gate_op: exp -> add -> rcp per gate; tanh(j), f * c, the cell fma,
-    its tanh chain, o * tanh(c); the two selects last), with every consumer at least two positions behind its producers
-    (a dependent instruction right behind a transcendental stalls the wave)."""
+    permutation that respects the update's data flow (gate_op: exp -> add -> rcp per gate, the o gate's reciprocal taken
+    together with tanh(c)'s; K tanh(j), f * c', the cell fma, 2^c', the common denominator and its reciprocal, 1 - 2^c', h;
+    the two selects last), with every consumer at least two positions behind its producers (a dependent instruction
+    right behind a transcendental stalls the wave)."""
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gym_collision_avoidance_amd", "csrc",
                             "cagpu_ga3c.inc")).read()
     n_ops = {k: int(v) for k, v in re.findall(r"constexpr int (GATE_OPS(?:_SEL)?) = (\d+);", src)}
-    assert n_ops == {"GATE_OPS": 84, "GATE_OPS_SEL": 92}
-    for name, steps in (("GATE_ORDER", 21), ("GATE_ORDER_SEL", 23)):
+    assert n_ops == {"GATE_OPS": 80, "GATE_OPS_SEL": 88}
+    for name, steps in (("GATE_ORDER", 20), ("GATE_ORDER_SEL", 22)):
         body = re.search(r"constexpr int %s\[GATE_OPS(?:_SEL)?\] = \{([^}]*)\};" % name, src).group(1)
         order = [int(x) for x in body.replace("\n", " ").split(",") if x.strip()]
         assert sorted(order) == list(range(4 * steps)), name
@@ -523,15 +524,15 @@ def test_ga3c_gate_micro_op_orders_are_schedules_of_the_cell_update():
         deps = {}
         for r in range(4):
             op = lambda s: 4 * s + r  # noqa: E731
-            for s in range(4, 12):
+            for s in range(4, 11):
                 deps[op(s)] = [op(s - 4)]
-            deps[op(12)], deps[op(13)] = [op(9)], [op(10)]
-            deps[op(14)] = [op(8), op(12), op(13)]
-            for s in range(15, 20):
-                deps[op(s)] = [op(s - 1)]
-            deps[op(20)] = [op(11), op(19)]
-            if steps > 21:
-                deps[op(21)], deps[op(22)] = [op(14), op(13)], [op(20)]
+            deps[op(11)], deps[op(12)] = [op(9)], [op(10)]
+            deps[op(13)] = [op(8), op(11), op(12)]
+            deps[op(14)], deps[op(15)] = [op(13)], [op(14)]
+            deps[op(16)], deps[op(17)] = [op(15), op(7)], [op(16)]
+            deps[op(18)], deps[op(19)] = [op(14)], [op(18), op(17)]
+            if steps > 20:
+                deps[op(20)], deps[op(21)] = [op(13), op(12)], [op(19)]
         for o, ds in deps.items():
             for d in ds:
                 assert pos[o] - pos[d] >= 2, (name, o, d, pos[o], pos[d])
