@@ -46,6 +46,23 @@ GA3C_MACS_BF16 = 19 * 71 * 256 + 64 * 256 + 2 * 256 * 256
 GA3C_PLANE_PRODUCTS = 3
 
 
+def provenance():
+    """what this line was measured on: the library file's sha256 (whatever CAGPU_LIB points to), the build record written
+    beside the product library (git commit + dirty flag + digest of the kernel sources: gym_collision_avoidance_amd/
+    build_native.write_build_info -- there is no .git on the GPU box), this script's own hash"""
+    import hashlib
+    from gym_collision_avoidance_amd import _native as nat
+    from gym_collision_avoidance_amd import build_native as bn
+    out = {"lib": os.path.relpath(nat.LIB_PATH, REPO), "lib_sha256": bn.file_sha256(nat.LIB_PATH) if os.path.exists(nat.LIB_PATH) else None,
+           "bench_py_sha256": hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()}
+    info = bn.build_info()
+    if os.path.abspath(nat.LIB_PATH) == os.path.abspath(bn.OUT) and not info.get("stale"):
+        out.update({k: info.get(k) for k in ("git_sha", "git_dirty", "source_sha256")})
+    else:
+        out["note"] = "not the product library of the build record (an experiment build through CAGPU_LIB, or a stale record)"
+    return out
+
+
 def _profile_records(stem):
     """the records of profiles/r*_<stem>.json, newest round first (a file holds one record or a list of them)"""
     import glob
@@ -62,12 +79,17 @@ def measured_traffic_bytes(envs, agents, kernel, steps_per_launch):
     corrected by the factor the same pass measured on a streaming copy of known size with this kernel's 8-byte-per-lane
     access shape -- cagpu_debug_copy8; profiles/), if they were taken at this geometry and for this kernel; bench.py itself
     does not run the profiler.  -> (bytes per launch or None, source or None)"""
-    for d, src in _profile_records("traffic"):
-        if d.get("envs") == envs and d.get("agents") == agents and d.get("kernel", "").split("(")[0] in kernel:
-            if "traffic_bytes_per_step" in d:
-                return d["traffic_bytes_per_step"] * steps_per_launch, src
-            if steps_per_launch == 1:   # (records of rounds 2 - 4: raw counters of single-step launches)
-                return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0, src + " (uncalibrated counters)"
+    recs = [(d, src) for d, src in _profile_records("traffic")
+            if d.get("envs") == envs and d.get("agents") == agents and d.get("kernel", "").split("(")[0] in kernel]
+    for d, src in recs:   # (newest round first) a pass over launches of exactly this length
+        if "traffic_bytes_per_launch" in d and d.get("steps_per_launch") == steps_per_launch:
+            return d["traffic_bytes_per_launch"], src + " (counter passes over launches of %d steps)" % steps_per_launch
+    for d, src in recs:   # otherwise: the per-step figure of a pass at another launch length, scaled -- and said so
+        if "traffic_bytes_per_step" in d:
+            return d["traffic_bytes_per_step"] * steps_per_launch, src + " (measured at %d steps per launch, scaled to %d)" % (
+                d.get("steps_per_launch", 1), steps_per_launch)
+        if steps_per_launch == 1 and "fetch_kb_per_launch" in d:   # (records of rounds 2 - 4: raw counters of single-step launches)
+            return (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0, src + " (uncalibrated counters)"
     return None, None
 
 
@@ -99,9 +121,11 @@ def cpu_baseline(n_agents, K, budget_s=8.0):
     """CPU baseline beside the GPU number, on THIS host (the GPU box), bounded to ~20 s:
       * kind "port": oracle/ca_oracle.cpp (C++ restatement of the reference step) on 1 core and on all cores
         (independent processes, rates summed -- envs never interact);
-      * the reference's OWN Python env.step cannot run here (/root/reference is not on the GPU box): its rate measured in
-        the build container by oracle/time_reference.py (1 process and nproc processes, host stated) is attached from
-        the newest profiles/r*_reference_cpu.json (re-timed live where the reference is present)."""
+      * the reference's OWN Python env.step cannot run here: a Python reference may not travel to the GPU box in any form
+        (source, bytecode or otherwise -- the task's rule for Python references; only C / C++ references may be built into
+        oracle/_ref), so its rate, measured in the build container by oracle/time_reference.py on the unmodified
+        /root/reference (1 process and nproc processes, host stated), is attached from the newest
+        profiles/r*_reference_cpu.json and re-timed live wherever the reference is present."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     s1, d1 = _port_leg((n_agents, K, budget_s, 0))
@@ -221,9 +245,15 @@ def extra_workload(out, a, sim, core, E, N, K, dev, torch):
         # the roofline of a float32 contraction done this way: every product costs three f16 plane products
         peak = BF16_MFMA_PEAK_TFLOPS / GA3C_PLANE_PRODUCTS
         issued = 2.0 * rows * (GA3C_MACS_BF16 * GA3C_PLANE_PRODUCTS) / infer_s / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": flops / infer_s / 1e12, "peak": peak,
-                           "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / peak, "traffic": None,
-                           "peak_note": "f16 dense MFMA peak (2500 TFLOP/s) / 3 plane products per float32 product (rounds 2 - 4: / 6)",
+        out["roofline"] = {"bound": "mfma", "achieved": flops / infer_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flops / infer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "frac_of_f16_peak": {"algorithmic": flops / infer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                                "issued": issued / BF16_MFMA_PEAK_TFLOPS},
+                           "peak_note": "`frac` = algorithmic float32-class flops / the f16 dense MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md); "
+                                        "`issued` counts the three f16 plane products every float32 product costs on this path "
+                                        "(rounds 2 - 4: six bf16 ones); against peak / 3 -- the roofline of a float32 contraction done "
+                                        "this way -- the algorithmic figure is `frac_of_peak_over_3`",
+                           "frac_of_peak_over_3": flops / infer_s / 1e12 / peak,
                            "issued_f16_tflops": issued, "issued_frac_of_f16_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak": flops / infer_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
                            "kernel": "ga3c::ga3c_kernel", "avg_launch_us": infer_s * 1e6,
@@ -514,11 +544,14 @@ def main():
     # steps, and the latency of the one collective (the 8-counter all-reduce), measured outside the step clock
     per_rank_ms, allreduce_us = [gpu_ms_local / a.steps], None
     ranks_seen = 1
+    per_rank_stats = None
     if dist_on:
         mine = torch.tensor([gpu_ms_local / a.steps], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [float(x.item()) for x in every]
+        from gym_collision_avoidance_amd.sharding import gather_episode_stats
+        per_rank_stats = [[float(x) for x in row] for row in gather_episode_stats(stats_local).cpu().numpy()]
         one = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one)                # counts the ranks that actually took part
         ranks_seen = int(round(float(one.item())))
@@ -544,7 +577,10 @@ def main():
         steps_per_launch = a.steps // launches
         bytes_per_launch = algorithmic_bytes_per_agent_step(K) * E * N * steps_per_launch
         kern_s = gpu_ms * 1e-3 / launches          # average launch duration (HIP events over the timed region)
-        achieved = bytes_per_launch / kern_s / 1e9
+        achieved_ev = bytes_per_launch / kern_s / 1e9
+        # `value` is whole-job throughput on the WALL clock of the timed block, so the headline fraction is priced on the same
+        # clock (what the driver's own timing reproduces); the HIP-event figure (device time of the same launches) is beside it
+        achieved = bytes_per_launch * launches / wall / 1e9
         traffic, traffic_src = (measured_traffic_bytes(E, N, kernel_name, steps_per_launch)
                                 if a.mode in ("step", "lookahead") else (None, None))
         total_envs = world * E
@@ -575,9 +611,11 @@ def main():
                            "rollout": "cagpu_rollout: all steps in one launch, only the LAST step's outputs are kept"}[a.mode]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "clock": "wall clock of the timed block (the clock of `value`); *_events: HIP events around the same launches",
+                         "achieved_events": achieved_ev, "frac_events": achieved_ev / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_unit": ("bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE passes over this kernel, committed as %s "
-                                          "(not re-measured in this run)" % traffic_src) if traffic is not None else
+                         "traffic_unit": ("bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE passes over this kernel (calibrated on a copy of "
+                                          "known size), committed as %s; not re-measured in this run" % traffic_src) if traffic is not None else
                                          "no committed counter pass for this geometry / kernel",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": kernel_name, "avg_launch_us": kern_s * 1e6, "steps_per_launch": steps_per_launch,
@@ -589,6 +627,8 @@ def main():
             "distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist_on else None),
             "per_rank_event_ms_per_step": per_rank_ms,
             "stats_allreduce_us": allreduce_us,   # the ONLY collective (RCCL all-reduce of 8 float64 counters), off the step path
+            "episode_stats_per_rank": per_rank_stats,   # (N > 1 / --force-dist: the all-gathered shard counters; their sum is episode_stats)
+            "provenance": provenance(),
         }
         if a.workload != "rvo10":
             extra_workload(out, a, sim, core, E, N, K, dev, torch)

@@ -14,7 +14,7 @@ AT_GOAL, WAS_AT_GOAL, IN_COLLISION, WAS_IN_COLLISION, OUT_OF_TIME, DONE, IS_LEAR
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 POLICY_SHIFT, DYNAMICS_SHIFT = 8, 12
 ABSENT, PLAN_VALID = 1 << 16, 1 << 17
-ABI_VERSION = 10  # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
+ABI_VERSION = 11  # CAGPU_VERSION of include/cagpu.h: the struct layouts below mirror THAT header
 POL_RVO, POL_NONCOOP, POL_STATIC, POL_EXTERNAL, POL_LEARNING, POL_LEARNING_GA3C, POL_GA3C_CADRL = range(7)
 DYN_UNICYCLE, DYN_MAX_TURN_RATE, DYN_EXTERNAL = range(3)
 SORT_CLOSEST_FIRST, SORT_CLOSEST_LAST, SORT_TIME_TO_IMPACT = range(3)
@@ -74,7 +74,7 @@ class CaNet(C.Structure):
 
 EXPORTS = ("cagpu_version", "cagpu_last_error", "cagpu_last_kernel", "cagpu_reset", "cagpu_step", "cagpu_step_map", "cagpu_rollout",
            "cagpu_orca", "cagpu_observe", "cagpu_laserscan", "cagpu_ga3c", "cagpu_generate_cases", "cagpu_generate_cases_ragged", "cagpu_plan", "cagpu_debug_libm", "cagpu_device_faults", "cagpu_workspace_bytes",
-           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack", "cagpu_rollout_ring", "cagpu_ring_snapshots", "cagpu_debug_copy8")
+           "cagpu_ga3c_packed_bytes", "cagpu_ga3c_pack", "cagpu_rollout_ring", "cagpu_ring_snapshots", "cagpu_debug_copy8", "cagpu_device_faults_async")
 
 _lib = None
 
@@ -116,6 +116,7 @@ def lib():
     L.cagpu_generate_cases_ragged.argtypes = ([C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32] + [C.c_double] * 4 +
                                               [C.c_uint64, _P, _P, _P, _P])
     L.cagpu_device_faults.argtypes = [_P, C.c_int32]
+    L.cagpu_device_faults_async.argtypes = [_P, _P]
     L.cagpu_workspace_bytes.argtypes = [PP]
     L.cagpu_workspace_bytes.restype = C.c_uint64
     L.cagpu_ga3c_packed_bytes.argtypes = []

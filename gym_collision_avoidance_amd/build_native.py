@@ -52,7 +52,63 @@ def build(force=False, verbose=False, variant=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    write_build_info()
     return OUT
+
+
+INFO = os.path.join(HERE, "_build_info.json")
+
+
+def source_digest():
+    """sha256 over the kernel sources + the header, in a fixed order: names the source tree a library was built from"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) + [os.path.join(REPO, "include", "cagpu.h")]:
+        path = f if os.path.isabs(f) else os.path.join(HERE, "csrc", f)
+        h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()
+
+
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def write_build_info():
+    """_build_info.json beside the product library (git-ignored, travels with it to the GPU box, where there is no .git):
+    the commit the tree stood at when the library was built, whether the tree was dirty, the digest of the kernel sources
+    and of the library itself.  bench.py stamps every line with it, profiles/make_r0N.py refuses to file artefacts that
+    carry different library hashes (a profile cannot go stale unnoticed: VERDICT r05 weak-3 / weak-13)."""
+    import json
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", REPO] + list(a), capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:  # noqa: BLE001
+            return ""
+    info = {"git_sha": git("rev-parse", "HEAD"), "git_dirty": bool(git("status", "--porcelain", "--", "gym_collision_avoidance_amd/csrc", "include")),
+            "source_sha256": source_digest(), "lib_sha256": file_sha256(OUT), "flags": " ".join(FLAGS)}
+    json.dump(info, open(INFO, "w"), indent=1)
+    return info
+
+
+def build_info():
+    """what write_build_info() recorded, checked against the library that is actually there -> dict (lib_sha256 is always
+    the hash of the file on disk; `stale` says the record was written for another file)"""
+    import json
+    info = {}
+    if os.path.exists(INFO):
+        try:
+            info = json.load(open(INFO))
+        except Exception:  # noqa: BLE001
+            info = {}
+    have = file_sha256(OUT) if os.path.exists(OUT) else None
+    info["stale"] = bool(info.get("lib_sha256") and info["lib_sha256"] != have)
+    info["lib_sha256"] = have
+    return info
 
 
 if __name__ == "__main__":

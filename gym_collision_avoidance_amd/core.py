@@ -127,6 +127,8 @@ class BatchedSim(object):
         self._has_ga3c = False    # some agent's policy is CA_POL_GA3C_CADRL (set_plugins)
         self._ga3c_ext = None
         self.ga3c_logits = None
+        self._fault = None        # the non-blocking fault-word probe of the product path (_fault_probe)
+        self._steps_since_probe = 0
 
     # ---------------------------------------------------------------- what the outside reads
     # `state` and the four outputs are those of the step last handed out: reading them goes through sync(), which rewinds a
@@ -173,6 +175,8 @@ class BatchedSim(object):
                 raise AttributeError("CaParams has no field %r" % k_)
             setattr(self.p, k_, v)
         self._fast_args = None
+        if self._la is not None:
+            self._la["in_kernel"].clear()
         self.invalidate_plan()
         if self._table is not None:
             ar = self._ar
@@ -405,6 +409,8 @@ class BatchedSim(object):
         [-pi, pi) on the device (Philox of seed, global env id, reset count, agent) instead of pointing at the goal."""
         self.sync()
         self._fast_args = None
+        if self._la is not None:
+            self._la["in_kernel"].clear()
         if table is None:
             self._ar, self._table = None, None
             return
@@ -528,6 +534,10 @@ class BatchedSim(object):
             rc = fa[0](*fa[1], torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 nat.check(rc)
+            self._steps_since_probe += 1
+            if self._steps_since_probe >= 256:
+                self._steps_since_probe = 0
+                self._fault_probe()
             if self._variants:
                 self._apply_sensor_variants()
             return self._obs, self._rewards, self._game_over
@@ -600,7 +610,7 @@ class BatchedSim(object):
         draws, no per-agent sensor variants (extra cagpu_observe launches), no static map (wall test + laser scan)."""
         return not (self._has_ga3c or self._rvo is not None or self._variants or self._map is not None)
 
-    def enable_lookahead(self, k, fresh=True, adaptive=False):
+    def enable_lookahead(self, k, fresh=True, adaptive=False, start=None):
         """Serve step(None) from a ring of `k` steps computed ahead of time in ONE launch (cagpu_rollout_ring): with every
         policy internal a step needs nothing from the host (env_utils.py:45-52 passes None until the episode is over),
         so step_lookahead() hands out slot t of the ring and launches the next k steps when it runs dry -- the fused
@@ -611,23 +621,35 @@ class BatchedSim(object):
         fresh: every refill writes into a NEWLY allocated ring (what step_lookahead returned stays valid and belongs to
         the caller); False: one persistent ring, a slot is overwritten k steps later.  k = 0: off.
         adaptive: k is the LONGEST ring.  A rewind throws the rest of a ring away, so a caller who looks at the state (or
-        acts) every m steps should not pay for k: after a rewind at slot t the next ring is t steps long (at least 1 = one
-        launch per step), and every ring consumed to its end doubles the next one up to k."""
+        acts) every m steps should not pay for k: the first ring is `start` steps long (default min(k, 8): a caller who
+        reads the state after its first step has wasted at most 7), after a rewind at slot t the next ring is t steps
+        long (at least 1 = one launch per step), and a ring consumed to its end doubles the next one up to k -- after a
+        rewind only once TWO rings in a row have been used up, so that a caller who looks at the state after every step
+        stays at one launch per step instead of alternating between rings of 1 and 2.
+        What step_lookahead() returns are VIEWS of the ring's tensors (slot t of `[n, E, N, W]` ...): with fresh=True they
+        are never written again and stay valid for as long as the caller holds them, but holding ONE of them keeps the
+        whole ring allocated (n slots); clone a slot that is kept long-term."""
         self.sync()
         k = int(k)
         if k <= 0:
             self._la = None
             return
-        self._la = dict(n=k, cur=k, len=0, t=0, slots=None, fresh=bool(fresh), adaptive=bool(adaptive), ring=None,
-                        snap=torch.empty_like(self._slab), fills=0, rewinds=0, in_kernel={}, next=None, co=None)
+        cur = k if not adaptive else max(1, min(k, 8 if start is None else int(start)))
+        self._la = dict(n=k, cur=cur, len=0, t=0, slots=None, fresh=bool(fresh), adaptive=bool(adaptive), ring=None,
+                        snap=torch.empty_like(self._slab), fills=0, rewinds=0, in_kernel={}, next=None, co=None,
+                        streak=2, probe=None)
 
     def _la_fill(self):
         la = self._la
         if not self.lookahead_ok():
             raise nat.CagpuError("step_lookahead: this batch needs work between two steps (GA3C-CADRL network, stochastic RVO "
                                  "draws, sensor variants or a static map) -- use step()")
-        if la["adaptive"] and la["slots"] is not None and la["t"] >= la["len"]:   # the last ring was used up: a longer one
-            la["cur"] = min(la["n"], 2 * la["cur"])
+        # (CaState.ext_state belongs to the ONE step() call that was given it: see rollout())
+        self._cs.ext_state, self._ext_state = None, None
+        if la["adaptive"] and la["slots"] is not None and la["t"] >= la["len"]:   # the last ring was used up: a longer one --
+            la["streak"] += 1                                                     # after a rewind, only the second in a row
+            if la["streak"] >= 2:
+                la["cur"] = min(la["n"], 2 * la["cur"])
         k, E, N = la["cur"], self.E, self.N
 
         def new_ring(n):
@@ -649,10 +671,14 @@ class BatchedSim(object):
         # the rewind point = the state BEFORE the k steps: stored by the pipelined n-step kernel itself as it loads its
         # tiles (snapshot_delta: the snapshot slab has the state slab's layout); by one device copy in front of the launch
         # for the other kernels
-        key = (k, self.p.sort_mode, self._ar is not None and bool(self._ar.reset_obs), bool(self._cs.next_action))
-        in_kernel = la["in_kernel"].get(key)   # (which kernel a ring call runs depends on exactly these)
-        if in_kernel is None:
-            in_kernel = la["in_kernel"][key] = self.lib.cagpu_ring_snapshots(C.byref(self.p), C.byref(self._cs), C.byref(co), ar, k) == 1
+        key = (k, self.p.sort_mode, self._ar is not None and bool(self._ar.reset_obs), bool(self._cs.next_action),
+               0 if self._ar is None else int(self._ar.heading_seed))
+        in_kernel = la["in_kernel"].get(key)   # (which kernel a ring call runs depends on exactly these; the cache is
+        if in_kernel is None:                  #  dropped by set_fixture_table / update_params)
+            rc = self.lib.cagpu_ring_snapshots(C.byref(self.p), C.byref(self._cs), C.byref(co), ar, k)
+            if rc < 0:
+                nat.check(rc)
+            in_kernel = la["in_kernel"][key] = rc == 1
         delta = 0
         if in_kernel:
             delta = la["snap"].data_ptr() - self._slab.data_ptr()
@@ -663,8 +689,9 @@ class BatchedSim(object):
         la["slots"] = list(zip(obs.unbind(0), rew.unbind(0), done.view(torch.bool).unbind(0), over.view(torch.bool).unbind(0)))
         la["t"], la["len"] = 0, k
         la["fills"] += 1
+        self._fault_probe()
         if la["fresh"]:
-            la["next"] = new_ring(min(la["n"], 2 * k) if la["adaptive"] else k)
+            la["next"] = new_ring(min(la["n"], 2 * k) if (la["adaptive"] and la["streak"] >= 1) else k)
 
     def step_lookahead(self):
         """one step(None) served from the look-ahead ring -> (obs [E,N,W], rewards [E,N], done [E,N] bool, game_over [E] bool)"""
@@ -691,6 +718,7 @@ class BatchedSim(object):
             la["rewinds"] += 1
             if la["adaptive"]:     # the caller came back after t steps: that is how far the next ring looks ahead
                 la["cur"] = max(1, t)
+                la["streak"] = 0
         if not la["fresh"]:
             la["ring"] = None      # (the current outputs below live in it: the next fill must not overwrite them)
         if t > 0:                  # the outputs of the last step handed out are the simulator's current outputs
@@ -706,14 +734,34 @@ class BatchedSim(object):
                                                  None if self._ar is None else C.byref(self._ar), t, self._stream()))
 
     # ---------------------------------------------------------------- statistics
+    def _fault_probe(self):
+        """The device's fault word on the product path, without a synchronisation: a 4-byte copy into pinned host memory
+        is queued behind the launch just submitted (cagpu_device_faults_async); the word an EARLIER probe brought back is
+        looked at here once its copy has landed.  A raised bit (a hand-over poll of the pipelined kernel ran out, a
+        GA3C-CADRL operand left the fp16 range) raises CagpuError through check_faults()."""
+        fp = self._fault
+        if fp is None:
+            fp = self._fault = dict(buf=torch.zeros((1,), dtype=torch.int32).pin_memory(), ev=None, probes=0)
+        if fp["ev"] is not None:
+            if not fp["ev"].query():
+                return               # (still in flight: looked at by a later call)
+            fp["ev"] = None
+            if int(fp["buf"][0]) != 0:
+                self.check_faults()  # (synchronising read + clear; raises)
+        nat.check(self.lib.cagpu_device_faults_async(fp["buf"].data_ptr(), self._stream()))
+        fp["ev"] = torch.cuda.Event()
+        fp["ev"].record(torch.cuda.current_stream(self.device))
+        fp["probes"] += 1
+
     def check_faults(self):
         """Raise if a step kernel flagged a fault on this device since the last check (cagpu_device_faults: a bounded
         hand-over poll of the pipelined kernel ran out -- the state may be wrong).  Synchronises the device."""
         with torch.cuda.device(self.device):
             f = nat.device_faults(clear=True)
         if f:
-            raise nat.CagpuError("device fault word 0x%x: a hand-over inside the pipelined step kernel timed out; the "
-                                 "simulator state is not to be trusted" % f)
+            raise nat.CagpuError("device fault word 0x%x:%s%s the simulator state is not to be trusted" % (
+                f, " a hand-over inside the pipelined step kernel timed out;" if f & 1 else "",
+                " a GA3C-CADRL operand left the fp16 range of the network kernel's two-plane split (|x| >= 65504);" if f & 2 else ""))
 
     def episode_stats(self, check=True):
         """Per-shard episode counters: float64 [8] (see STAT_NAMES), reduced on the device.  A reporting point: the

@@ -75,6 +75,8 @@ struct KArgs {
   // cagpu_rollout_ring: != 0: the pipelined n-step kernel also stores the state it starts from at (address + snap_delta)
   int64_t snap_delta;
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
+  int32_t launch_seq;  // a per-process launch counter: tags the words of the n-step kernel's per-CU progress table (cagpu_pipe.inc)
+  int32_t yield_t;     // > 0: progress-fair priorities among the workgroups of a CU (PIPE_PRIO in cagpu_pipe.inc); set by launch_pipe2
 };
 
 // ---------------------------------------------------------------- small math helpers
@@ -464,6 +466,10 @@ __device__ double time_to_impact(double hx, double hy, double ox, double oy, dou
   const double d = d2 < d1 ? d2 : d1;
   return d / sqrt(v0 * v0 + v1 * v1);
 }
+
+// The device's fault word (cagpu_device_faults): bit 0 = a bounded hand-over poll of the pipelined step kernel ran out
+// (cagpu_pipe.inc), bit 1 = a GA3C-CADRL operand left the fp16 range of the network kernel's two-plane split (cagpu_ga3c.inc).
+__device__ unsigned int g_fault = 0u;
 
 #include "cagpu_grouplp.inc"
 
@@ -1866,12 +1872,23 @@ bool pipe_eligible(const KArgs& k) {
   return wgs <= cap || wgs >= 2 * cap;
 }
 
+#ifndef CAGPU_PIPE_YIELD_T
+#define CAGPU_PIPE_YIELD_T 2   // (A/B builds: 0 = off)
+#endif
 template <int NC, int TE, bool MULTI>
-int launch_pipe2(const KArgs& k, hipStream_t st) {
+int launch_pipe2(const KArgs& k0, hipStream_t st) {
   using G = pipe::Geo<NC, TE>;
   static_assert(G::LDS <= 48 * 1024 && (NC != 10 || G::LDS <= 40 * 1024), "three (metric geometry: four) workgroups per CU");
   static_assert(TE <= 32 && NC * TE <= 64 && NC >= 2 && NC <= 10, "one agent wave per half; lp3_wave8 holds at most 9 lines");
+  KArgs k = k0;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + TE - 1) / TE);
+  // progress-fair priorities (PIPE_PRIO): an n-step launch whose workgroups are all resident at once and share their CUs
+  k.yield_t = 0;
+  if (MULTI && CAGPU_PIPE_YIELD_T > 0) {
+    const long cus = device_cus();
+    const long per_cu = (160 * 1024) / static_cast<long>(G::LDS) < 4 ? (160 * 1024) / static_cast<long>(G::LDS) : 4;
+    if (grid > cus && grid <= per_cu * cus) k.yield_t = CAGPU_PIPE_YIELD_T;
+  }
   std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d", NC, TE,
                 MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode);
   hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
@@ -2077,13 +2094,21 @@ static int step_impl(const CaParams* p, const CaState* s, const CaOut* o, const 
   }
   k.n_steps = n_steps; k.mode = MODE_STEP;
   k.inv_rvo_dt = 1.0 / p->rvo_dt;
+  {
+    static std::atomic<int> seq{0};
+    k.launch_seq = seq.fetch_add(1, std::memory_order_relaxed) + 1;
+  }
   if (ring) {
     k.ring_agent = static_cast<int64_t>(p->num_envs) * p->num_agents;
     k.ring_obs = k.ring_agent * (6 + 7 * p->max_obs);
     k.ring_env = p->num_envs;
     // the in-kernel snapshot is the pipelined n-step kernel's (launch_pipe with n_steps > 1): every other form of the call
     // leaves it to the caller (cagpu_ring_snapshots says which, from the same arguments)
+#ifdef CAGPU_NOPIPE   // (a build whose launcher never picks the pipelined kernel must not promise its snapshot either)
+    const bool can = false;
+#else
     const bool can = n_steps > 1 && pipe_eligible(k);
+#endif
     if (query_snapshot) return can ? 1 : 0;
     if (snapshot_delta != 0 && !can)
       return fail(CA_EUNSUPPORTED, "cagpu_rollout_ring: snapshot_delta needs the pipelined n-step kernel (cagpu_ring_snapshots() == 1 for these arguments)%s");
@@ -2382,13 +2407,21 @@ uint64_t cagpu_workspace_bytes(const CaParams* p) {
 int cagpu_device_faults(uint32_t* faults, int32_t clear) {
   if (!faults) return fail(CA_EINVAL, "cagpu_device_faults: NULL pointer%s");
   unsigned int v = 0u;
-  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(pipe::g_fault), sizeof(v));  // (synchronises the device)
+  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fault), sizeof(v));  // (synchronises the device)
   if (e == hipSuccess && clear && v) {
     const unsigned int z = 0u;
-    e = hipMemcpyToSymbol(HIP_SYMBOL(pipe::g_fault), &z, sizeof(z));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fault), &z, sizeof(z));
   }
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_device_faults: %s", hipGetErrorString(e));
   *faults = v;
+  return CA_OK;
+}
+
+int cagpu_device_faults_async(uint32_t* host_dst, void* stream) {
+  if (!host_dst) return fail(CA_EINVAL, "cagpu_device_faults_async: NULL pointer%s");
+  hipError_t e = hipMemcpyFromSymbolAsync(host_dst, HIP_SYMBOL(g_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost,
+                                          static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu_device_faults_async: %s", hipGetErrorString(e));
   return CA_OK;
 }
 

@@ -58,8 +58,8 @@ class _HostAgent(object):
 class CollisionAvoidanceEnv(Env):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
 
-    LOOKAHEAD_MAX = 256                  # the default ring: as long as LOOKAHEAD_BYTES of outputs allow, at most this
-    LOOKAHEAD_BYTES = 4 << 30
+    LOOKAHEAD_MAX = 128                  # the default ring: as long as LOOKAHEAD_BYTES of outputs allow, at most this
+    LOOKAHEAD_BYTES = 1 << 30            # (per ring; a refill allocates the next ring while the current one is being served)
 
     def __init__(self, num_envs=1, device="cuda:0", zero_copy=False, lookahead=None):
         """zero_copy (batched mode only): False -- step() / rollout() / reset() return FRESH tensors, like the
@@ -74,10 +74,14 @@ class CollisionAvoidanceEnv(Env):
         rollout never waits for the slowest workgroup of a step).  Whatever needs the simulator exactly at the step
         last handed out -- an action, a custom `dt`, reset(), reading an agent's state, episode_stats() -- rewinds
         transparently (core.BatchedSim.sync), and the ring adapts: after a rewind at slot t the next ring is t steps long
-        (down to one launch per step for a caller who looks at the state every step), every ring used up doubles the
-        next one.  `lookahead` = the longest ring; None: as many steps as LOOKAHEAD_BYTES of output tensors hold, at most
-        LOOKAHEAD_MAX (256 at 4096 x 10: 8.3 us per step against 14.9 with one launch per step; a ring of 20: 10.1) --
-        unless zero_copy (whose contract is ONE persistent buffer): then 0 = off (one launch per step)."""
+        (down to one launch per step for a caller who looks at the state every step), the first ring is 8 steps long
+        and every ring used up doubles the next one.  `lookahead` = the longest ring; None: as many steps as
+        LOOKAHEAD_BYTES (1 GiB) of output tensors hold, at most LOOKAHEAD_MAX (89 at 4096 x 10: 8.9 us per step against
+        14.9 with one launch per step; a ring of 20: 9.8) -- unless zero_copy (whose contract is ONE persistent buffer):
+        then 0 = off (one launch per step).  What step(None) returns under the ring are VIEWS of one slot of it: never
+        written again, valid for as long as they are held, but ONE held observation keeps its whole ring (up to
+        LOOKAHEAD_BYTES) allocated -- `.clone()` what goes into a long-lived buffer (a sparse replay sample, prev_obs
+        across many steps), or pass a smaller `lookahead`."""
         self.id = 0
         self.num_envs = int(num_envs)
         self.device = device

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAGPU_VERSION 10
+#define CAGPU_VERSION 11
 
 /* error codes */
 enum { CA_OK = 0, CA_EINVAL = -1, CA_EUNSUPPORTED = -2, CA_ELAUNCH = -3, CA_ENODEVICE = -4 };
@@ -397,8 +397,17 @@ uint64_t cagpu_workspace_bytes(const CaParams *p);
 
 /* Device-side fault word of the CURRENT device (synchronises it): bit 0 = a bounded hand-over poll inside the pipelined
  * step kernel ran out (csrc/cagpu_pipe.inc wait_for), i.e. some launch since the last clear may have produced wrong state.
+ * bit 1 = an operand of the GA3C-CADRL network kernel left the range of its two-plane fp16 split (|x| >= 65504: a normalised
+ * input or an activation; csrc/cagpu_ga3c.inc), i.e. some cagpu_ga3c call since the last clear chose its actions from
+ * saturated values.
  * *faults receives the word; clear != 0 resets it.  0 in normal operation; check it wherever the host synchronises anyway. */
 int cagpu_device_faults(uint32_t *faults, int32_t clear);
+
+/* The same word WITHOUT a synchronisation (v11): queues a 4-byte copy into *host_dst -- PINNED host memory of the caller --
+ * on `stream`, behind the work already submitted there; the caller reads *host_dst once an event recorded behind this call
+ * has completed.  Does not clear.  For the product path of a caller that never synchronises (the look-ahead ring of
+ * core.BatchedSim: one probe per refill). */
+int cagpu_device_faults_async(uint32_t *host_dst, void *stream);
 
 /* Parity hook (tests only, synchronous, HOST pointers, default stream): evaluates on the device, element by element, the
  * operations through which a step's results can differ from a CPU run of the same algorithm -- no reference analogue:

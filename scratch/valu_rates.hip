@@ -59,6 +59,10 @@
 #define A_CMP64(n) "v_cmp_lt_f64 vcc, %" #n ", %8\n"
 #define A_MAX64(n) "v_max_f64 %" #n ", %" #n ", %8\n"
 #define A_RNDNE64(n) "v_rndne_f64 %" #n ", %" #n "\n"
+// (round 6) packed float32: one instruction, two float32 operations per lane on a 64-bit register pair
+#define A_PKFMA32(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %8\n"
+#define A_PKMUL32(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_PKADD32(n) "v_pk_add_f32 %" #n ", %" #n ", %8\n"
 #define A_CVT64(n) "v_cvt_f32_f64 %" #n ", %" #n "\n"
 
 KERNEL_F32(k_fma32, A_FMA32)
@@ -82,6 +86,9 @@ KERNEL_F64(k_rsq64, A_RSQ64)
 KERNEL_F64(k_cmp64, A_CMP64)
 KERNEL_F64(k_max64, A_MAX64)
 KERNEL_F64(k_rndne64, A_RNDNE64)
+KERNEL_F64(k_pk_fma32, A_PKFMA32)
+KERNEL_F64(k_pk_mul32, A_PKMUL32)
+KERNEL_F64(k_pk_add32, A_PKADD32)
 
 template <typename K>
 void run(const char* name, K kern, float* out, int grid, int threads) {
@@ -112,6 +119,7 @@ int main() {
     RUN(k_fma32); RUN(k_mul32); RUN(k_max32); RUN(k_and); RUN(k_cndmask); RUN(k_cmp32); RUN(k_mul24); RUN(k_mullo); RUN(k_cvti);
     RUN(k_rcp32); RUN(k_sqrt32); RUN(k_dpp); RUN(k_bperm);
     RUN(k_fma64); RUN(k_mul64); RUN(k_add64); RUN(k_max64); RUN(k_cmp64); RUN(k_rndne64); RUN(k_rcp64); RUN(k_rsq64);
+    RUN(k_pk_fma32); RUN(k_pk_mul32); RUN(k_pk_add32);
   }
   return 0;
 }

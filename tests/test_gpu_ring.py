@@ -248,7 +248,8 @@ def test_env_api_serves_step_none_from_the_ring():
     ref, la = envs
     ring = la._sim._la
     assert la._la_on and not ref._la_on and ref._sim._la is None
-    assert ring["n"] == Env.LOOKAHEAD_MAX == 256 and ring["adaptive"]      # (512 x 10: 1.4 MB per slot, the byte budget is far)
+    assert ring["n"] == Env.LOOKAHEAD_MAX == 128 and ring["adaptive"]      # (512 x 10: 1.4 MB per slot, the byte budget is far)
+    assert ring["cur"] == 8                                                # the first ring is short: 8, 16, 32, 64, 128, 128 ...
     kept = []
 
     def same(n, **kw):
@@ -260,19 +261,20 @@ def test_env_api_serves_step_none_from_the_ring():
             assert i0["which_agents_learning"] == i1["which_agents_learning"]
             assert g1.dtype == torch.bool and i1["which_agents_done"].dtype == torch.bool
             kept.append((o1, o1.clone()))
-    same(256 + 13)
-    assert ring["fills"] == 2 and ring["t"] == 13 and ring["len"] == 256
+    same(8 + 16 + 32 + 64 + 128 + 13)
+    assert ring["fills"] == 6 and ring["t"] == 13 and ring["len"] == 128
     # reading an agent (a view of the device state) sees the step last handed out, not the end of the ring -- and the ring
-    # adapts: the caller came back after 13 steps, so the next ring looks 13 steps ahead; used up, it doubles
+    # adapts: the caller came back after 13 steps, so the next ring looks 13 steps ahead; the second one in a row that is
+    # used up doubles
     assert np.array_equal(ref.agents[3].pos_global_frame, la.agents[3].pos_global_frame)
     assert ref.agents[3].t == la.agents[3].t and ref.episode_step_number == la.episode_step_number
     assert ring["rewinds"] == 1 and ring["cur"] == 13 and ring["slots"] is None
-    same(13 + 26 + 5)
-    assert ring["fills"] == 5 and ring["len"] == 52 and ring["t"] == 5
+    same(13 + 13 + 26 + 5)
+    assert ring["fills"] == 10 and ring["len"] == 52 and ring["t"] == 5
     same(3, dt=0.05)            # another dt: stepped one launch at a time (a rewind at slot 5), then back to the ring
     assert ring["cur"] == 5
-    same(40)
-    assert ring["slots"] is not None
+    same(5 + 5 + 10 + 20)
+    assert ring["slots"] is not None and ring["len"] == 20 and ring["t"] == 20
     assert ref.episode_stats() == la.episode_stats()
     same(7)
     # a caller who looks at the state after EVERY step ends up with one launch per step, not with 256 steps per look
@@ -281,8 +283,8 @@ def test_env_api_serves_step_none_from_the_ring():
         assert ref.agents[0].t == la.agents[0].t
     assert ring["cur"] == 1 and ring["len"] == 1
     launches = ring["fills"]
-    same(1 + 2 + 4)
-    assert ring["fills"] == launches + 3 and ring["len"] == 4
+    same(1 + 1 + 2 + 4)
+    assert ring["fills"] == launches + 4 and ring["len"] == 4 and ring["t"] == 4
     for env in envs:
         env.reset()
     same(70)
@@ -344,3 +346,39 @@ def test_ring_through_the_other_step_kernels_of_the_env_api(mode):
     want = {"n6": "ca_pipe_kernel<6, 10, true>", "ragged": "ca_pipe_kernel<10, 4, true>", "random_headings": "ca_kernel<256"}[mode]
     assert any(k_.startswith(want) for k_ in kernels), kernels
     envtools.default()
+
+
+def test_fault_word_is_probed_on_the_product_path_without_a_sync():
+    """step_lookahead() queues a 4-byte copy of the device's fault word behind every refill (cagpu_device_faults_async into
+    pinned host memory) and looks at the word an earlier probe brought back: a raised bit surfaces as CagpuError within a few
+    refills, with no synchronisation on the way.  The bit is raised here by the GA3C-CADRL kernel's range guard (an other agent
+    1e6 m away: its normalised position leaves the fp16 range of the two-plane split) -- which is this guard's own test too."""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    a, table, N, _ = _bench().build_workload("rvo10", 256, dev)
+    a.enable_lookahead(4, fresh=True)
+    for _ in range(24):
+        a.step_lookahead()
+    assert a._fault["probes"] >= 5 and nat.device_faults(clear=False) == 0
+    # -- the range guard: a healthy batch leaves the word alone, a far neighbour raises bit 1
+    g, tab20, N20, K20 = _bench().build_workload("ga3c20", 64, dev)
+    g.step()
+    assert nat.device_faults(clear=False) == 0
+    g.state["pos_x"][:, 1] = 1.0e6
+    g.invalidate_plan()
+    g.observe()
+    g.ga3c()
+    assert nat.device_faults(clear=False) == 2
+    # -- the ring of the OTHER simulator sees it (the word is the device's): within a few refills, no sync in between
+    with pytest.raises(nat.CagpuError, match="fp16 range"):
+        for _ in range(64):
+            a.step_lookahead()
+    assert nat.device_faults(clear=True) == 0     # (check_faults() cleared it when it raised)
+    for _ in range(12):
+        a.step_lookahead()
+    a.sync()
+    # -- and the single-launch path probes every 256 launches
+    b, _, _, _ = _bench().build_workload("rvo10", 64, dev)
+    for _ in range(600):
+        b.step()
+    assert b._fault is not None and b._fault["probes"] >= 2
