@@ -1889,8 +1889,8 @@ int launch_pipe2(const KArgs& k0, hipStream_t st) {
     const long per_cu = (160 * 1024) / static_cast<long>(G::LDS) < 4 ? (160 * 1024) / static_cast<long>(G::LDS) : 4;
     if (grid > cus && grid <= per_cu * cus) k.yield_t = CAGPU_PIPE_YIELD_T;
   }
-  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d", NC, TE,
-                MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode);
+  std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d%s", NC, TE,
+                MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode, k.yield_t > 0 ? " fair" : "");
   hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
@@ -1911,6 +1911,10 @@ int launch_pipe(const KArgs& k, hipStream_t st) {
     // vs 12.83 at 2048, 14.69 vs 14.05 at 3072 (profiles/r04_kernel_geometry.md).  A workgroup's duration is its serial
     // chain (a tile alone on a CU still needs ~9.5 us), not its pair work, so four times as many workgroups only add their
     // fixed costs and contend for the issue slots the chains need.
+    // Round 6, the same question in ring mode (2- and 1-env tiles for grids of at most one 4-env workgroup per CU, same box,
+    // 1024 x 10): ring of 64 8.10 -> 8.08 / 7.99 us per step, ring of 20 9.40 -> 9.40 / 9.46, 2000-step rollout 6.73 -> 6.57 / 6.45,
+    // one launch per step 11.78 -> 11.92 / 12.18: below the 0.5 us bar in every mode a caller sees; not built
+    // (profiles/r06_kernel_geometry.md).
     case 10: return launch_pipe1<10, 4>(k, st);
 #ifndef CAGPU_FAST
     case 8: return launch_pipe1<8, 8>(k, st);

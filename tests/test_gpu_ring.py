@@ -359,7 +359,7 @@ def test_fault_word_is_probed_on_the_product_path_without_a_sync():
     a.enable_lookahead(4, fresh=True)
     for _ in range(24):
         a.step_lookahead()
-    assert a._fault["probes"] >= 5 and nat.device_faults(clear=False) == 0
+    assert a._fault["probes"] >= 2 and nat.device_faults(clear=False) == 0   # (a probe still in flight is not doubled)
     # -- the range guard: a healthy batch leaves the word alone, a far neighbour raises bit 1
     g, tab20, N20, K20 = _bench().build_workload("ga3c20", 64, dev)
     g.step()
