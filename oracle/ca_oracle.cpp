@@ -547,6 +547,8 @@ int ca_oracle_rollout(const OrcParams* p, const OrcState* s, const OrcOut* o, co
   return ca_oracle_rollout_ex(p, s, o, nullptr, table, n_cases, env_id_offset, case_stride, n_steps, nullptr);
 }
 
+void ca_oracle_set_tie_order(int reverse) { orca_ref::g_tie_reverse = reverse ? 1 : 0; }  // (tests only: see orca_ref.h)
+
 void ca_oracle_set_libm(double (*atan2_fn)(double, double), void (*sincos_fn)(double, double*, double*)) {
   g_atan2 = atan2_fn;
   g_sincos = sincos_fn;

@@ -296,5 +296,12 @@ def set_libm(atan2_fn=None, sincos_fn=None):
     L.ca_oracle_set_libm(C.cast(a, C.c_void_p) if a else None, C.cast(b, C.c_void_p) if b else None)
 
 
+def set_tie_order(reverse=False):
+    """tests only: exactly tied distSq neighbours in reverse visit order (orca_ref.h g_tie_reverse); process-wide"""
+    L = lib()
+    L.ca_oracle_set_tie_order.restype = None
+    L.ca_oracle_set_tie_order(C.c_int(1 if reverse else 0))
+
+
 def round2(x):
     return lib().ca_oracle_round2(float(x))

@@ -61,6 +61,11 @@ struct Body {  // what one simulated agent carries into a step
 // insertion with strict `<` so ties keep visit (= index) order, capped at max_nb
 // (Agent::insertAgentNeighbor).  Visit order is index order, which is what the library's
 // kd-tree yields while the agent count does not exceed its leaf size (10).
+// g_tie_reverse (tests only, ca_oracle_set_tie_order): exactly tied distSq entries in REVERSE visit order -- the other order
+// a kd-tree build of the library could visit them in once an env holds more than MAX_LEAF_SIZE = 10 agents (upstream's tree
+// permutes its agent array, and keeps the permutation from step to step).  tests/test_orca_semantics.py uses it to bound what
+// the visit order of tied neighbours can change at all on the N = 20 / 50 fixtures.
+static int g_tie_reverse = 0;
 static inline void neighbours(const Body* a, size_t n, size_t self, float range_sq, size_t max_nb,
                               std::vector<std::pair<float, size_t> >& out) {
   out.clear();
@@ -71,7 +76,7 @@ static inline void neighbours(const Body* a, size_t n, size_t self, float range_
     if (d2 < range_sq) {
       if (out.size() < max_nb) out.push_back(std::make_pair(d2, j));
       size_t i = out.size() - 1;
-      while (i != 0 && d2 < out[i - 1].first) {
+      while (i != 0 && (d2 < out[i - 1].first || (g_tie_reverse && d2 == out[i - 1].first))) {
         out[i] = out[i - 1];
         --i;
       }
