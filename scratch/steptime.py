@@ -42,8 +42,28 @@ def balance():
     torch.cuda.synchronize()
 
 
+tile_map = torch.arange(T4, dtype=torch.int32, device=torch.device("cuda", 0))
+
+
+def deal_tiles():
+    """BALANCE=cu (round 6; needs the `tilemap` plumbing of commit "tile-map probe" -- KArgs.tile_map + cagpu_debug_set_tile_map,
+    removed from the product sources after the measurement, profiles/r06_kernel_geometry.md): tiles stay as they are, but the block -> tile table deals them to the CUs (block b runs on
+    CU b mod 256) snake-wise by planned-agent count, so that every CU's four tiles carry about the same total"""
+    f = sim.state["flags"]
+    cnt = ((f & (nat.AT_GOAL | nat.OUT_OF_TIME | nat.IN_COLLISION | nat.ABSENT)) == 0).sum(dim=1).view(T4, 4).sum(dim=1)
+    order = torch.argsort(cnt, descending=True, stable=True)          # order[r] = the tile of rank r
+    r = torch.arange(T4, device=f.device)
+    rnd, pos = r // 256, r % 256
+    block = torch.where(rnd % 2 == 0, pos, 255 - pos) + 256 * rnd
+    tile_map[block] = order.to(torch.int32)
+    torch.cuda.synchronize()
+    lib.cagpu_debug_set_tile_map(C.c_void_p(tile_map.data_ptr()))
+
+
 for rep in range(12):
-    if BAL:
+    if BAL == "cu":
+        deal_tiles()
+    elif BAL:
         balance()
     sim.rollout(L)
     lib.cagpu_debug_steptime(buf)
