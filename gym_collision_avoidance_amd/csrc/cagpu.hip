@@ -1597,6 +1597,10 @@ LP1_UNROLL
     ka->s.step_num[i] = r.step_num;
     if (a == 0) { ka->s.episode_step[e] = ep_step; ka->s.reset_count[e] = reset_cnt; }
   }
+  // (Round 6, measured and dropped: the list of the agents the NEXT network query evaluates, packed here by every tile -- one
+  //  epoch-tagged device-scope atomic per tile for its range + one arrival ticket -- so that cagpu_ga3c could skip its packing
+  //  launch (6.9 us of a 143 us config-3 step).  1 366 tiles x 2 same-address atomics cost ~43 ns each, serialised: the step
+  //  kernel went 34 -> 129 us (config 3: 146 -> 241 us per step, same box).  compact_kernel does the same with 80 workgroups.)
 #ifdef CAGPU_WGTIME
   if (tid == 0 && blockIdx.x < 4096) {
     unsigned hw = 0, xcc = 0;
@@ -1870,6 +1874,12 @@ bool pipe_eligible(const KArgs& k) {
   if (n != 10) return true;
   const long wgs = (static_cast<long>(k.p.num_envs) + 3) / 4, cap = 4L * device_cus();
   return wgs <= cap || wgs >= 2 * cap;
+}
+
+// the epoch tags of the GA3C-CADRL packing counters (ga3c::tagged_add): no two packings of a process share a tag
+uint32_t next_pack_epoch() {
+  static std::atomic<uint32_t> epoch_source{static_cast<uint32_t>(std::chrono::steady_clock::now().time_since_epoch().count())};
+  return epoch_source.fetch_add(1, std::memory_order_relaxed);
 }
 
 #ifndef CAGPU_PIPE_YIELD_T
@@ -2198,8 +2208,7 @@ int cagpu_ga3c(const CaParams* p, const CaState* s, const float* obs, const CaNe
     if (k.B >= (1L << 31)) return fail(CA_EUNSUPPORTED, "cagpu_ga3c: more than 2^31 agents with rows_scratch%s");
     // the packing's two counters are tagged with this call's epoch (compact_kernel): nothing to clear, whatever an earlier
     // launch or the caller's allocation left in the scratch; rows_scratch must hold num_envs * num_agents + 6 words
-    static std::atomic<uint32_t> epoch_source{static_cast<uint32_t>(std::chrono::steady_clock::now().time_since_epoch().count())};
-    const uint32_t epoch = epoch_source.fetch_add(1, std::memory_order_relaxed);
+    const uint32_t epoch = next_pack_epoch();
     hipLaunchKernelGGL(ga3c::compact_kernel, dim3(static_cast<unsigned>((k.B + 4 * ga3c::CP_NT - 1) / (4 * ga3c::CP_NT))),
                        dim3(ga3c::CP_NT), 0, static_cast<hipStream_t>(stream), s->flags, k.B, net->rows_scratch, net->agent_net,
                        net->net_index, epoch);
