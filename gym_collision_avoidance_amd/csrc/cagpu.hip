@@ -1901,7 +1901,8 @@ int launch_pipe2(const KArgs& k0, hipStream_t st) {
   }
   std::snprintf(g_last_kernel, sizeof(g_last_kernel), "ca_pipe_kernel<%d, %d, %s> grid=%u lds=%zu mode=%d%s", NC, TE,
                 MULTI ? "true" : "false", grid, static_cast<size_t>(G::LDS), k.mode, k.yield_t > 0 ? " fair" : "");
-  hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
+  if (MULTI && k.yield_t > 0) hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI, MULTI>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
+  else hipLaunchKernelGGL((pipe::ca_pipe_kernel<NC, TE, MULTI, false>), dim3(grid), dim3(pipe::PNT), G::LDS, st, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CA_ELAUNCH, "cagpu: kernel launch failed: %s", hipGetErrorString(e));
   return CA_OK;
