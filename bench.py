@@ -190,12 +190,21 @@ def env_api_rates(E, N, steps, torch, dev):
             env = CollisionAvoidanceEnv(num_envs=E, device=str(dev), **kw)
             env.set_fixture_suite(N)
             env.reset()
-            ring = env._sim._la["n"] if env._sim._la is not None else 0
-            # (the ring variant: warm up over two WHOLE rings -- the allocator then holds the blocks the fresh rings alternate
-            # between -- and time whole rings, so that exactly the steps that are served are computed inside the clock)
+            la = env._sim._la
+            ring = la["n"] if la is not None else 0
+            # (the ring variant: the adaptive ring starts at 8 steps and doubles -- warm up until it has reached its full length,
+            # two more WHOLE rings -- the allocator then holds the blocks the fresh rings alternate between --, stand at a ring
+            # boundary, and time whole rings, so that exactly the steps that are served are computed inside the clock)
             n_t = max(2, steps // ring) * ring if ring else steps
-            for _ in range(2 * ring if ring else 128):
+            for _ in range(128):
                 env.step(None)
+            if ring:
+                guard = 0
+                while (la["len"] != ring or la["t"] < la["len"]) and guard < 16 * ring:
+                    env.step(None)
+                    guard += 1
+                for _ in range(2 * ring):
+                    env.step(None)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(n_t):

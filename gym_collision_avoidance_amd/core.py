@@ -129,7 +129,9 @@ class BatchedSim(object):
         self._ga3c_ext = None
         self.ga3c_logits = None
         self._fault = None        # the non-blocking fault-word probe of the product path (_fault_probe)
-        self._steps_since_probe = 0
+        # (the first probe -- it creates the side stream and the pinned word: milliseconds -- on the second launch of a
+        # simulator's life, not 256 launches in, in the middle of somebody's timed loop)
+        self._steps_since_probe = 254
 
     # ---------------------------------------------------------------- what the outside reads
     # `state` and the four outputs are those of the step last handed out: reading them goes through sync(), which rewinds a
