@@ -757,6 +757,8 @@ class BatchedSim(object):
         is queued behind the launch just submitted (cagpu_device_faults_async); the word an EARLIER probe brought back is
         looked at here once its copy has landed.  A raised bit (a hand-over poll of the pipelined kernel ran out, a
         GA3C-CADRL operand left the fp16 range) raises CagpuError through check_faults()."""
+        if torch.cuda.is_current_stream_capturing():
+            return                   # (a step captured into a HIP graph: events and side streams have no place in the capture)
         fp = self._fault
         if fp is None:
             # the copy runs on a stream of its own: the word is a device global that kernels OR bits into, so the read needs

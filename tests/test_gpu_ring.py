@@ -382,3 +382,33 @@ def test_fault_word_is_probed_on_the_product_path_without_a_sync():
     for _ in range(600):
         b.step()
     assert b._fault is not None and b._fault["probes"] >= 2
+
+
+def test_steps_captured_into_a_hip_graph_replay_bit_for_bit():
+    """`sim.step()` stays capturable (bench.py --mode graph, the two-stream extra): the fault-word probe of the product path --
+    an event query + a copy on a side stream -- stands back while the current stream is capturing, also when its turn (every 256
+    launches; the first one on a simulator's second launch) falls inside the capture"""
+    nat, core, orc = _mods()
+    dev = torch.device("cuda", 0)
+    a, table, N, _ = _bench().build_workload("rvo10", 512, dev)
+    b, _, _, _ = _bench().build_workload("rvo10", 512, dev)
+    assert b._steps_since_probe >= 250 and b._fault is None      # (its first probe is due inside the capture below)
+    for _ in range(7):
+        a.step()
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        b.step()                                                  # (warm-up on the capture stream, as torch asks)
+    torch.cuda.current_stream(dev).wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(3):
+            b.step()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    _same_state(a, b, "after 1 eager + 2 x 3 replayed steps")
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards)
+    for _ in range(300):                                          # the probe takes up its work again outside the capture
+        b.step()
+    assert b._fault is not None and b._fault["probes"] >= 1
