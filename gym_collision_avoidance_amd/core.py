@@ -773,10 +773,11 @@ class BatchedSim(object):
             fp["busy"] = False
             if int(fp["buf"][0]) != 0:
                 self.check_faults()  # (synchronising read + clear; raises)
-        rc = self.lib.cagpu_device_faults_async(*fp["h"])
-        if rc != 0:
-            nat.check(rc)
-        fp["ev"].record(fp["stream"])
+        with torch.cuda.device(self.device):     # (the word is the CURRENT device's symbol: a process that drives several GPUs)
+            rc = self.lib.cagpu_device_faults_async(*fp["h"])
+            if rc != 0:
+                nat.check(rc)
+            fp["ev"].record(fp["stream"])
         fp["busy"] = True
         fp["probes"] += 1
 
