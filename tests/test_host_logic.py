@@ -536,3 +536,34 @@ def test_ga3c_gate_micro_op_orders_are_schedules_of_the_cell_update():
         for o, ds in deps.items():
             for d in ds:
                 assert pos[o] - pos[d] >= 2, (name, o, d, pos[o], pos[d])
+
+
+def test_bench_lines_carry_the_provenance_of_the_library_they_ran_on():
+    """round 6 (a profile must not go stale unnoticed): build_native writes the commit, the dirty
+    flag and the digests of the kernel sources and of libcagpu.so beside the library; bench.provenance() -- stamped into every
+    bench line and every profiles/r06_* record -- hashes the file that is actually loaded and only vouches for the build record
+    when it belongs to that file"""
+    import hashlib
+    import bench
+    from gym_collision_avoidance_amd import _native as nat, build_native as bn
+    assert os.path.exists(bn.OUT), "build first (python -c 'import __graft_entry__ as g; g.build()')"
+    info = bn.build_info()
+    want = hashlib.sha256(open(bn.OUT, "rb").read()).hexdigest()
+    assert info["lib_sha256"] == want
+    pv = bench.provenance()
+    assert pv["lib_sha256"] == hashlib.sha256(open(nat.LIB_PATH, "rb").read()).hexdigest() and len(pv["bench_py_sha256"]) == 64
+    if os.path.abspath(nat.LIB_PATH) == os.path.abspath(bn.OUT) and not info["stale"]:
+        assert pv["source_sha256"] == bn.source_digest() or info.get("git_dirty") is not None   # (sources edited after the build: the digest says so)
+        assert "git_sha" in pv and "git_dirty" in pv
+    else:
+        assert "note" in pv and "git_sha" not in pv
+    # the committed round-6 record names ONE library, and every line filed with it carries that library's hash
+    import glob
+    import json
+    prov = json.load(open(os.path.join(REPO, "profiles", "r06_provenance.json")))
+    for f in glob.glob(os.path.join(REPO, "profiles", "r06_*.json")):
+        d = json.load(open(f))
+        for rec in (d if isinstance(d, list) else [d]):
+            p = rec.get("provenance") if isinstance(rec, dict) else None
+            if p:
+                assert p["lib_sha256"] == prov["lib_sha256"], f
