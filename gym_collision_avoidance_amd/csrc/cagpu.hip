@@ -76,6 +76,7 @@ struct KArgs {
   int64_t snap_delta;
   int32_t ablate;  // timing experiments only (-DCAGPU_ABLATE + env CAGPU_ABLATE); 0 in product builds
   int32_t launch_seq;  // a per-process launch counter: tags the words of the n-step kernel's per-CU progress table (cagpu_pipe.inc)
+  float inv_h_f, inv_dt_f;  // pipelined kernels: 1.0f / float(p.rvo_time_horizon), 1.0f / float(p.rvo_dt) -- IEEE float quotients, set by launch_pipe2
   int32_t yield_t;     // > 0: progress-fair priorities among the workgroups of a CU (PIPE_PRIO in cagpu_pipe.inc); set by launch_pipe2
 };
 
@@ -1892,6 +1893,8 @@ int launch_pipe2(const KArgs& k0, hipStream_t st) {
   static_assert(TE <= 32 && NC * TE <= 64 && NC >= 2 && NC <= 10, "one agent wave per half; lp3_wave8 holds at most 9 lines");
   KArgs k = k0;
   const unsigned grid = static_cast<unsigned>((k.p.num_envs + TE - 1) / TE);
+  k.inv_h_f = 1.0f / static_cast<float>(k.p.rvo_time_horizon);   // (x86 float division: correctly rounded, like the device's `/`)
+  k.inv_dt_f = 1.0f / static_cast<float>(k.p.rvo_dt);
   // progress-fair priorities (PIPE_PRIO): an n-step launch whose workgroups are all resident at once and share their CUs
   k.yield_t = 0;
   if (MULTI && CAGPU_PIPE_YIELD_T > 0) {
