@@ -15,23 +15,37 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "r06")
 DST = os.path.join(REPO, "profiles")
 E, N, ALG = 4096, 10, 356.0
-KM, KS = "ca_pipe_kernel<10, 4, true>", "ca_pipe_kernel<10, 4, false>"
+KM, KS = "ca_pipe_kernel<10, 4, true>", "ca_pipe_kernel<10, 4, false>"   # as cagpu_last_kernel() / the bench lines name them
+# ... and as the profiler names the instantiations (round 6: the fourth template parameter is FAIR, the progress-fair priorities)
+PROF = {KM: "ca_pipe_kernel<10, 4, true, true>", KS: "ca_pipe_kernel<10, 4, false, false>"}
 L_PMC = 20      # steps per launch of the counter passes over the n-step kernel: the length the driver's command times
+
+
+def _one_run(d, pattern):
+    """the csv files of ONE profiler run under gpurun_out/r06/<d>: gpurun merges a call's outputs INTO the local directory, so
+    files of an earlier call (another process id in the name) survive unless the directory is cleared first -- averaging them
+    in is how a profile goes stale; refuse"""
+    files = glob.glob(os.path.join(SRC, d, "**", pattern), recursive=True)
+    runs = {os.path.basename(f).split("_")[0] for f in files}
+    if len(runs) > 1:
+        raise SystemExit("profiles/make_r06.py: %s holds the output of %d profiler runs (%s): rm -rf gpurun_out/r06 before the "
+                         "measurement call and run it again" % (d, len(runs), sorted(runs)))
+    return files
 
 
 def pmc(d, kernel, skip=1):
     """{counter: mean per dispatch of `kernel`}, the first `skip` dispatches left out (set-up launches); + their number"""
     acc = {}
-    for f in glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in _one_run(d, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"]:
+            if PROF.get(kernel, kernel) in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: sum(v[skip:]) / max(1, len(v) - skip) for k, v in acc.items()}, {k: len(v) - skip for k, v in acc.items()}
 
 
 def kstats(d, needle):
-    for f in glob.glob(os.path.join(SRC, d, "**", "*kernel_stats.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if needle in r["Name"]]
+    for f in _one_run(d, "*kernel_stats.csv"):
+        rows = [r for r in csv.DictReader(open(f)) if PROF.get(needle, needle) in r["Name"]]
         rows.sort(key=lambda r: -int(r["Calls"]))
         if rows:
             r = rows[0]
@@ -68,7 +82,7 @@ json.dump(PROV, open(os.path.join(DST, "r06_provenance.json"), "w"), indent=1)
 # ---- counter calibration: cagpu_debug_copy8 moves exactly 8 n bytes each way with the step kernels' access shape
 cal = {}
 for d, c in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
-    for f in glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in _one_run(d, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if "copy8_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 n_el = 5_000_000 if int(r["Grid_Size"]) < 10_000_000 else 50_000_000
@@ -98,6 +112,8 @@ for kern, dirs, per in ((KM, ("prof_fetch", "prof_write"), L_PMC), (KS, ("prof_f
                                    "--pmc passes: FETCH_SIZE reports 1 / %.3f of the bytes read, WRITE_SIZE 1 / %.3f of the bytes "
                                    "written (scratch/copy8_calib.py; gpurun_out/r06/calib_*)" % (f_fetch, f_write),
                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), scratch/measure_r06.sh; %d dispatches; KB = 1024 B" % nf["FETCH_SIZE"]})
+if len(traffic) != 2:
+    raise SystemExit("profiles/make_r06.py: no counter rows for %s / %s under gpurun_out/r06 (kernel names changed?)" % (PROF[KM], PROF[KS]))
 json.dump(traffic, open(os.path.join(DST, "r06_traffic.json"), "w"), indent=1)
 
 valu = []

@@ -5,7 +5,8 @@
 # length the driver's command times (20 steps per launch) --, the counter calibration launches, one bench line per BASELINE
 # config (config 3 also with fused sensing), the same-box A/B of this round's progress-fair priorities, and the kernel traces of
 # the config-3 / config-5 runs.  Every bench line carries `provenance` (library sha256, git commit of the build);
-# profiles/make_r06.py refuses to file lines of different libraries together.
+# profiles/make_r06.py refuses to file lines of different libraries together -- and profiler output of more than one call: gpurun
+# MERGES a call's files into the local gpurun_out/, so `rm -rf gpurun_out/r06` in the build container before this call.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06
 rm -rf $O
