@@ -53,8 +53,11 @@ def provenance():
     import hashlib
     from gym_collision_avoidance_amd import _native as nat
     from gym_collision_avoidance_amd import build_native as bn
+    host = hashlib.sha256()   # the host side of the path: the binding and the batched-state layer (ring bookkeeping, probes)
+    for f in ("_native.py", "core.py", "sharding.py"):
+        host.update(f.encode() + b"\0" + open(os.path.join(REPO, "gym_collision_avoidance_amd", f), "rb").read())
     out = {"lib": os.path.relpath(nat.LIB_PATH, REPO), "lib_sha256": bn.file_sha256(nat.LIB_PATH) if os.path.exists(nat.LIB_PATH) else None,
-           "bench_py_sha256": hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()}
+           "bench_py_sha256": hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest(), "host_py_sha256": host.hexdigest()}
     info = bn.build_info()
     if os.path.abspath(nat.LIB_PATH) == os.path.abspath(bn.OUT) and not info.get("stale"):
         out.update({k: info.get(k) for k in ("git_sha", "git_dirty", "source_sha256")})

@@ -54,6 +54,8 @@ GA3C_DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 
 
 
 class BatchedSim(object):
+    PROBE_EVERY = 8   # the device's fault word is probed behind every 8th ring refill (and every 256th single launch)
+
     def __init__(self, params, device="cuda:0", record_actions=False, pipeline=True):
         """pipeline: hand the kernels CaState.next_action (include/cagpu.h): the step kernel then computes the RVO policy of
         the NEXT step beside the sensing half of this one and the next launch starts at the move -- bit-identical results.
@@ -674,7 +676,8 @@ class BatchedSim(object):
         la["co_live"] = prep["co"]      # (keeps the ctypes struct the launch was given alive)
         la["t"], la["len"] = 0, k
         la["fills"] += 1
-        self._fault_probe()
+        if la["fills"] % self.PROBE_EVERY == 1:   # (every refill costs a 20-step block 2.6 us: a second queue for the caller's
+            self._fault_probe()                   #  synchronisation to wait on; r06_kernel_geometry.md section 7)
         if la["fresh"]:                 # the next ring (tensors, views, arguments), allocated behind this launch
             la["prep"] = self._la_prepare(min(la["n"], 2 * k) if (la["adaptive"] and la["streak"] >= 1) else k)
 

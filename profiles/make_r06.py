@@ -72,11 +72,13 @@ for n in names:
 # ---- provenance: every line of this record was measured on ONE library (a profile must not go
 # stale unnoticed).  The A/B lines (ab_*) name other libraries on purpose and are filed as a text table with their hashes.
 prov = json.load(open(os.path.join(SRC, "provenance.json")))
-bad = {n: d.get("provenance", {}).get("lib_sha256") for n, d in lines.items() if d.get("provenance", {}).get("lib_sha256") != prov["lib_sha256"]}
+bad = {n: d.get("provenance", {}).get("lib_sha256") for n, d in lines.items()
+       if d.get("provenance", {}).get("lib_sha256") != prov["lib_sha256"] or d.get("provenance", {}).get("host_py_sha256") != prov.get("host_py_sha256")}
 if bad:
     raise SystemExit("profiles/make_r06.py: lines measured on another library than %s: %s" % (prov["lib_sha256"], bad))
 print("provenance: lib %s  git %s%s  sources %s" % (prov["lib_sha256"][:16], (prov.get("git_sha") or "?")[:12], " (dirty)" if prov.get("git_dirty") else "", (prov.get("source_sha256") or "?")[:16]))
-PROV = {"lib_sha256": prov["lib_sha256"], "git_sha": prov.get("git_sha"), "git_dirty": prov.get("git_dirty"), "source_sha256": prov.get("source_sha256")}
+PROV = {"lib_sha256": prov["lib_sha256"], "git_sha": prov.get("git_sha"), "git_dirty": prov.get("git_dirty"), "source_sha256": prov.get("source_sha256"),
+        "host_py_sha256": prov.get("host_py_sha256")}
 json.dump(PROV, open(os.path.join(DST, "r06_provenance.json"), "w"), indent=1)
 
 # ---- counter calibration: cagpu_debug_copy8 moves exactly 8 n bytes each way with the step kernels' access shape

@@ -357,9 +357,9 @@ def test_fault_word_is_probed_on_the_product_path_without_a_sync():
     dev = torch.device("cuda", 0)
     a, table, N, _ = _bench().build_workload("rvo10", 256, dev)
     a.enable_lookahead(4, fresh=True)
-    for _ in range(24):
+    for _ in range(4 * (2 * core.BatchedSim.PROBE_EVERY + 2)):
         a.step_lookahead()
-    assert a._fault["probes"] >= 2 and nat.device_faults(clear=False) == 0   # (a probe still in flight is not doubled)
+    assert a._fault["probes"] >= 2 and nat.device_faults(clear=False) == 0   # (every PROBE_EVERY-th refill; one in flight is not doubled)
     # -- the range guard: a healthy batch leaves the word alone, a far neighbour raises bit 1
     g, tab20, N20, K20 = _bench().build_workload("ga3c20", 64, dev)
     g.step()
@@ -371,7 +371,7 @@ def test_fault_word_is_probed_on_the_product_path_without_a_sync():
     assert nat.device_faults(clear=False) == 2
     # -- the ring of the OTHER simulator sees it (the word is the device's): within a few refills, no sync in between
     with pytest.raises(nat.CagpuError, match="fp16 range"):
-        for _ in range(64):
+        for _ in range(4 * (3 * core.BatchedSim.PROBE_EVERY + 2)):   # (one probe to fetch the word, the next one to look at it)
             a.step_lookahead()
     assert nat.device_faults(clear=True) == 0     # (check_faults() cleared it when it raised)
     for _ in range(12):
