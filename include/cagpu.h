@@ -12,8 +12,11 @@
  *     until the stream reaches the call.  The library never allocates or frees device memory.
  *   - CaParams / CaState / CaOut / CaAutoReset are HOST structs, copied at call time.
  *   - asynchronous and stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the
- *     default stream).  Re-entrant across streams and devices; the only global is the
- *     thread-local last-error string.
+ *     default stream).  Re-entrant across streams and devices; the only host global is the
+ *     thread-local last-error string.  Device globals: the fault word (cagpu_device_faults) and
+ *     the per-CU progress table of the n-step kernel's progress-fair priorities -- words tagged
+ *     with a per-process launch counter, read for issue priorities only: concurrent launches can
+ *     perturb each other's priorities through it, never their results.
  *   - returns 0 on success, a negative CA_E* code otherwise; never throws across the boundary.
  *   - layout: agent-major SoA, index e*num_agents + a (agent fastest), one array per field, so a
  *     wavefront's 64 lanes load 64 consecutive elements.  State is float64 because the
